@@ -1,0 +1,44 @@
+// hvd_kernels.h -- internal launch interface between the C-ABI host layer
+// (hvd_api.cpp) and the gfx950 kernels (k_hamming.hip, k_pdq.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hvd_mi355x.h"
+
+namespace hvd {
+
+struct AllPairsArgs {
+    const void* d_db;        // n * 32 bytes
+    uint32_t n;
+    const int32_t* d_group;  // nullable
+    uint32_t max_dist;
+    uint32_t rank, world;
+    hvd_pair* d_pairs;
+    unsigned long long cap;
+    unsigned long long* d_count;
+    int variant;
+    uint32_t col_chunk;      // 0 = pick automatically
+};
+
+hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s);
+
+hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t max_dist,
+                            uint32_t* d_tflags, int32_t* d_hits, hipStream_t s);
+
+// PDQ frame hashing. d_dct: 16*64 floats (host-computed, uploaded once).
+// kind 0: gray u8 64x64 frames; kind 1: float 64x64 buffers (output of the
+// down-sampler). d_in strides are implied by kind.
+hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
+                             int32_t* d_quality, hipStream_t s);
+
+// Luma + 2x Jarosz box filter + decimate to 64x64 float, for h,w != 64 (the
+// reference's 512x512 rgb24 frames, vpdqpy/vpdqpy.py:90-95,113).
+// d_ws: min(n,1024) * pdq_downsample_ws_floats(h,w) floats of workspace.
+size_t pdq_downsample_ws_floats(int h, int w);
+hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int w, int channels, float* d_ws,
+                                 float* d_out64, hipStream_t s);
+// 64x64 rgb24 frames: luma only (no blur, as upstream's 64x64 shortcut).
+hipError_t launch_pdq_luma64_rgb(const uint8_t* d_frames, int64_t n, float* d_out64, hipStream_t s);
+
+}  // namespace hvd

@@ -1,0 +1,267 @@
+// k_hamming.hip -- all-pairs 256-bit Hamming kernels for gfx950 (MI355X).
+//
+// Replaces the per-pair vpdq.matchHashBytes calls of the reference's VP-tree search
+// (db/vptree.py:29-31,737; dedup.py:445-502) by a brute-force pass over the strict
+// upper triangle of the pair matrix.
+//
+// Mapping (wave64, integer VALU bound -- this is not GEMM-shaped work for MFMA in
+// its popcount form):
+//   * a workgroup of 256 lanes owns 256*R query rows; each lane keeps its R query
+//     hashes (8 dwords each) in VGPRs for the whole tile;
+//   * candidate hashes are wave-uniform, so they are fetched with scalar loads
+//     (s_load_dwordx8/x16 through the scalar cache) and used as SGPR operands:
+//     one comparison = 8 v_xor_b32 + 8 v_bcnt_u32_b32 (popcount with accumulate);
+//   * hits (distance <= max_dist) are rare; a wave-uniform branch leads to the
+//     append path (one global atomic per hit);
+//   * grid = (row blocks) x (column chunks); tiles below the diagonal exit at once,
+//     tile (rb,cb) is owned by rank (rb+cb) % world for the multi-GPU split.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvd_kernels.h"
+
+namespace {
+
+// One 32-bit slice of a comparison: XOR with the (SGPR) candidate word, then
+// v_bcnt_u32_b32's fused "popcount + accumulate". Written as asm because LLVM
+// re-associates popcount sums into bcnt(x,0) + v_add3 chains (19 VALU per comparison
+// instead of the minimal 16).
+__device__ __forceinline__ uint32_t xpop0(uint32_t q, uint32_t c) {
+    uint32_t t, d;
+    asm("v_xor_b32 %0, %1, %2" : "=v"(t) : "s"(c), "v"(q));
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(d) : "v"(t));
+    return d;
+}
+__device__ __forceinline__ uint32_t xpop(uint32_t q, uint32_t c, uint32_t acc) {
+    uint32_t t, d;
+    asm("v_xor_b32 %0, %1, %2" : "=v"(t) : "s"(c), "v"(q));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(t), "v"(acc));
+    return d;
+}
+
+__device__ __forceinline__ uint32_t ham_lo(const uint32_t (&q)[8], const uint32_t (&c)[8]) {
+    uint32_t d = xpop0(q[0], c[0]);
+    d = xpop(q[1], c[1], d);
+    d = xpop(q[2], c[2], d);
+    d = xpop(q[3], c[3], d);
+    return d;
+}
+__device__ __forceinline__ uint32_t ham_hi(const uint32_t (&q)[8], const uint32_t (&c)[8], uint32_t d) {
+    d = xpop(q[4], c[4], d);
+    d = xpop(q[5], c[5], d);
+    d = xpop(q[6], c[6], d);
+    d = xpop(q[7], c[7], d);
+    return d;
+}
+
+// Plain C++ version for the small kernels (operands in VGPRs).
+__device__ __forceinline__ uint32_t ham256(const uint32_t (&q)[8], uint32_t c0, uint32_t c1, uint32_t c2,
+                                           uint32_t c3, uint32_t c4, uint32_t c5, uint32_t c6, uint32_t c7) {
+    uint32_t d = __popc(q[0] ^ c0);
+    d += __popc(q[1] ^ c1);
+    d += __popc(q[2] ^ c2);
+    d += __popc(q[3] ^ c3);
+    d += __popc(q[4] ^ c4);
+    d += __popc(q[5] ^ c5);
+    d += __popc(q[6] ^ c6);
+    d += __popc(q[7] ^ c7);
+    return d;
+}
+
+__device__ __forceinline__ void append_pair(hvd_pair* out, unsigned long long cap, unsigned long long* count,
+                                            uint32_t i, uint32_t j, uint32_t dist) {
+    unsigned long long slot = atomicAdd(count, 1ull);
+    if (slot < cap) {
+        hvd_pair p;
+        p.i = i;
+        p.j = j;
+        p.dist = dist;
+        p.pad = 0;
+        out[slot] = p;
+    }
+}
+
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
+
+// Compare U consecutive candidates (j..j+U-1, wave-uniform, scalar-loaded) against
+// the R query rows of every lane. PREFILTER: look at the first 128 bits first and
+// skip the second half when no lane of the wave can still reach max_dist (exact: a
+// partial distance above the bound implies a full distance above it).
+template <int R, int U, bool PREFILTER>
+__device__ __forceinline__ void compare_group(const uint32_t* __restrict__ db, uint32_t j,
+                                              const uint32_t (&q)[R][8], const uint32_t (&row)[R],
+                                              const int32_t* __restrict__ group, uint32_t max_dist,
+                                              hvd_pair* __restrict__ out, unsigned long long cap,
+                                              unsigned long long* __restrict__ count) {
+    uint32_t c[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int w = 0; w < 8; ++w) c[u][w] = db[(size_t)(j + u) * 8u + w];  // uniform -> s_load
+
+    uint32_t d[U][R];
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) d[u][r] = ham_lo(q[r], c[u]);
+    if (PREFILTER) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) m = min(m, d[u][r]);
+        if (__builtin_expect(!__any(m <= max_dist), 1)) return;
+        m = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) d[u][r] = ham_hi(q[r], c[u], d[u][r]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) m = min(m, d[u][r]);
+    if (__builtin_expect(__any(m <= max_dist), 0)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (d[u][r] <= max_dist && row[r] < j + u) {
+                    if (group == nullptr || group[row[r]] != group[j + u])
+                        append_pair(out, cap, count, row[r], j + u, d[u][r]);
+                }
+            }
+    }
+}
+
+// R query rows per lane, U candidates per loop trip.
+template <int R, int U, bool PREFILTER>
+__global__ __launch_bounds__(256) void k_allpairs(const uint32_t* __restrict__ db, uint32_t n,
+                                                  const int32_t* __restrict__ group, uint32_t max_dist,
+                                                  uint32_t col_chunk, uint32_t rank, uint32_t world,
+                                                  hvd_pair* __restrict__ out, unsigned long long cap,
+                                                  unsigned long long* __restrict__ count) {
+    constexpr uint32_t ROWS = 256u * R;
+    const uint32_t rb = blockIdx.x, cb = blockIdx.y;
+    const uint32_t row0 = rb * ROWS;
+    const uint32_t col0 = cb * col_chunk;
+    const uint32_t col1 = min(col0 + col_chunk, n);
+    if (col1 <= row0 + 1u) return;               // tile entirely on/below the diagonal
+    if (world > 1u && (rb + cb) % world != rank) return;
+
+    uint32_t q[R][8];
+    uint32_t row[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        row[r] = row0 + (uint32_t)r * 256u + threadIdx.x;
+        if (row[r] < n) {
+            const uint4* p = reinterpret_cast<const uint4*>(db + (size_t)row[r] * 8u);
+            uint4 lo = p[0], hi = p[1];
+            q[r][0] = lo.x; q[r][1] = lo.y; q[r][2] = lo.z; q[r][3] = lo.w;
+            q[r][4] = hi.x; q[r][5] = hi.y; q[r][6] = hi.z; q[r][7] = hi.w;
+        } else {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) q[r][w] = 0u;
+            row[r] = 0xFFFFFFFFu;                 // never < j
+        }
+    }
+
+    uint32_t j = max(col0, row0 + 1u);
+    for (; j + U <= col1; j += U) compare_group<R, U, PREFILTER>(db, j, q, row, group, max_dist, out, cap, count);
+    for (; j < col1; ++j) compare_group<R, 1, PREFILTER>(db, j, q, row, group, max_dist, out, cap, count);
+}
+
+// One vpdq.matchHash call (vpdqpy/vpdqpy.py:56): q_hits / t_hits of a (na frames)
+// against b (nb frames). Single workgroup; lanes stride over frames of a, every lane
+// scans all frames of b. hit bitmaps live in global scratch supplied by the host.
+__global__ __launch_bounds__(256) void k_match_two(const uint32_t* __restrict__ a, uint32_t na,
+                                                   const uint32_t* __restrict__ b, uint32_t nb, uint32_t max_dist,
+                                                   uint32_t* __restrict__ t_flags, int32_t* __restrict__ out_hits) {
+    __shared__ uint32_t s_q, s_t;
+    if (threadIdx.x == 0) {
+        s_q = 0;
+        s_t = 0;
+    }
+    for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) t_flags[j] = 0u;
+    __syncthreads();
+    uint32_t my_q = 0;
+    for (uint32_t i = threadIdx.x; i < na; i += blockDim.x) {
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = a[(size_t)i * 8u + w];
+        bool any = false;
+        for (uint32_t j = 0; j < nb; ++j) {
+            const uint32_t* c = b + (size_t)j * 8u;
+            uint32_t d = ham256(q, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+            if (d <= max_dist) {
+                any = true;
+                t_flags[j] = 1u;  // benign race: all writers store 1
+            }
+        }
+        my_q += any ? 1u : 0u;
+    }
+    atomicAdd(&s_q, my_q);
+    __threadfence_block();
+    __syncthreads();
+    uint32_t my_t = 0;
+    for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) my_t += t_flags[j];
+    atomicAdd(&s_t, my_t);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out_hits[0] = (int32_t)s_q;
+        out_hits[1] = (int32_t)s_t;
+    }
+}
+
+}  // namespace
+
+namespace hvd {
+
+// Column chunk so that the launch has >= ~4k useful tiles (>> 256 CUs) while a
+// workgroup still amortises its query loads over >= 256 candidates.
+static uint32_t pick_col_chunk(uint32_t n, uint32_t rows_per_wg) {
+    uint64_t n_rb = (n + rows_per_wg - 1) / rows_per_wg;
+    uint64_t want_cb = (8192 + n_rb - 1) / n_rb;  // useful tiles ~ n_rb*n_cb/2
+    if (want_cb < 1) want_cb = 1;
+    uint64_t chunk = (n + want_cb - 1) / want_cb;
+    if (chunk < 256) chunk = 256;
+    if (chunk > 4096) chunk = 4096;
+    chunk = (chunk + 7) & ~7ull;
+    return (uint32_t)chunk;
+}
+
+template <int R, int U, bool PF>
+static hipError_t launch_allpairs_t(const AllPairsArgs& a, hipStream_t s) {
+    constexpr uint32_t ROWS = 256u * R;
+    uint32_t chunk = a.col_chunk ? a.col_chunk : pick_col_chunk(a.n, ROWS);
+    dim3 grid((a.n + ROWS - 1) / ROWS, (a.n + chunk - 1) / chunk);
+    if (grid.y > 65535u) {  // keep grid.y legal for any n < 2^32
+        chunk = ((a.n + 65534u) / 65535u + 7u) & ~7u;
+        grid.y = (a.n + chunk - 1) / chunk;
+    }
+    hipLaunchKernelGGL((k_allpairs<R, U, PF>), grid, dim3(256), 0, s, (const uint32_t*)a.d_db, a.n, a.d_group,
+                       a.max_dist, chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s) {
+    if (a.n < 2) return hipSuccess;
+    switch (a.variant) {
+        case 0: return launch_allpairs_t<4, 4, false>(a, s);
+        case 1: return launch_allpairs_t<4, 4, true>(a, s);
+        case 2: return launch_allpairs_t<8, 2, false>(a, s);
+        case 3: return launch_allpairs_t<8, 2, true>(a, s);
+        case 4: return launch_allpairs_t<2, 8, false>(a, s);
+        case 5: return launch_allpairs_t<4, 2, false>(a, s);
+        case 6: return launch_allpairs_t<4, 8, false>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t max_dist,
+                            uint32_t* d_tflags, int32_t* d_hits, hipStream_t s) {
+    hipLaunchKernelGGL(k_match_two, dim3(1), dim3(256), 0, s, d_a, na, d_b, nb, max_dist, d_tflags, d_hits);
+    return hipGetLastError();
+}
+
+}  // namespace hvd

@@ -1,0 +1,357 @@
+// k_pdq.hip -- PDQ frame hashing for gfx950 (MI355X).
+//
+// Replaces the per-frame arithmetic behind vpdq.VideoHasher.hash_frame
+// (reference vpdqpy/vpdqpy.py:113-119): luma -> [Jarosz blur -> decimate] -> 64x64
+// -> quality metric -> 16x16 DCT -> median -> 256 bits, laid out as
+// db/DedupeDB.py:535-559 describes (bit k=i*16+j at byte k>>3, bit k&7).
+//
+// Bit-exactness contract (oracle/hvd_oracle.c): every float op is a separately
+// rounded binary32 op in the oracle's order. All arithmetic that must match uses
+// __fmul_rn/__fadd_rn/__fsub_rn/__fdiv_rn, which hipcc never contracts into FMA,
+// and the DCT matrix is computed on the host in double and uploaded.
+// The f32 MFMA is an fmaf chain (one rounding per product+add) and therefore NOT
+// bit-identical to the reference's mul-then-add on x86-64; the DCT runs on the VALU.
+//
+// k_pdq_hash64: one wave64 per frame, 4 frames per workgroup, persistent grid.
+//   stage 0  lane j loads column j of the 64x64 frame (64 values in VGPRs)
+//   quality  vertical gradients in-lane, horizontal ones via the neighbour lane
+//   stage 1  T = D*A: lane j owns column j, D[i][k] is wave-uniform -> scalar
+//            loads, SGPR operands; 4 independent k-sequential chains per pass
+//   stage 2  B = T*D^T through LDS (T: 16x64, padded), lane l -> (i0=l>>4, j=l&15),
+//            4 outputs per lane; D rows come from a padded LDS copy
+//   median   radix select of the 128th smallest of 256 keys with wave ballots
+//   bits     ballot(B > median): lane l, output r is hash bit l + 64 r
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvd_kernels.h"
+
+namespace {
+
+constexpr int kWaves = 4;       // frames in flight per workgroup
+constexpr int kLd = 68;         // padded LDS row stride (floats): 272 B, 16-B aligned, bank-skewed
+
+struct alignas(16) PdqLds {
+    float T[kWaves][16][kLd];
+    float D[16][kLd];
+};
+
+__device__ __forceinline__ float luma_gray(uint32_t g) {
+    const float v = (float)g;
+    float y = __fmul_rn(0.299f, v);
+    y = __fadd_rn(y, __fmul_rn(0.587f, v));
+    y = __fadd_rn(y, __fmul_rn(0.114f, v));
+    return y;
+}
+
+// |(int)(((u - v) * 100) / 255)| as a non-negative integer (pdqhashing.cpp quality metric).
+__device__ __forceinline__ int grad_term(float u, float v) {
+    const float x = __fmul_rn(__fsub_rn(u, v), 100.0f);
+    const int d = (int)__fdiv_rn(x, 255.0f);
+    return d < 0 ? -d : d;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// KIND 0: uint8 gray 64x64 frames. KIND 1: float 64x64 buffers (down-sampler output).
+template <int KIND>
+__global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in, long long n,
+                                                    const float* __restrict__ dct, uint8_t* __restrict__ hashes,
+                                                    int32_t* __restrict__ quality) {
+    __shared__ PdqLds lds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // Padded LDS copy of the DCT matrix for stage 2 (once per workgroup).
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) lds.D[e >> 6][e & 63] = dct[e];
+    __syncthreads();
+
+    const long long groups = (n + kWaves - 1) / kWaves;
+    for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const long long f = g * kWaves + wave;
+        const bool valid = f < n;  // wave-uniform
+
+        if (valid) {
+            // ---- stage 0: column `lane` of the frame -------------------------------
+            float a[64];
+            if (KIND == 0) {
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(in) + f * 4096 + lane;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) a[k] = luma_gray(src[k * 64]);
+            } else {
+                const float* src = reinterpret_cast<const float*>(in) + f * 4096 + lane;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) a[k] = src[k * 64];
+            }
+
+            // ---- quality -----------------------------------------------------------
+            int gsum = 0;
+#pragma unroll
+            for (int k = 0; k < 63; ++k) gsum += grad_term(a[k], a[k + 1]);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                const float right = __shfl_down(a[k], 1, 64);
+                const int t = grad_term(a[k], right);
+                gsum += (lane < 63) ? t : 0;
+            }
+            gsum = wave_sum_i32(gsum);
+            int qual = gsum / 90;
+            qual = qual > 100 ? 100 : qual;
+
+            // ---- stage 1: T[i][lane] = sum_k D[i][k] * a[k], k ascending ------------
+#pragma unroll 1
+            for (int i0 = 0; i0 < 16; i0 += 4) {
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                const float* d0 = dct + (i0 + 0) * 64;  // wave-uniform -> s_load
+                const float* d1 = dct + (i0 + 1) * 64;
+                const float* d2 = dct + (i0 + 2) * 64;
+                const float* d3 = dct + (i0 + 3) * 64;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    s0 = __fadd_rn(s0, __fmul_rn(d0[k], a[k]));
+                    s1 = __fadd_rn(s1, __fmul_rn(d1[k], a[k]));
+                    s2 = __fadd_rn(s2, __fmul_rn(d2[k], a[k]));
+                    s3 = __fadd_rn(s3, __fmul_rn(d3[k], a[k]));
+                }
+                lds.T[wave][i0 + 0][lane] = s0;
+                lds.T[wave][i0 + 1][lane] = s1;
+                lds.T[wave][i0 + 2][lane] = s2;
+                lds.T[wave][i0 + 3][lane] = s3;
+            }
+            if (lane == 0) quality[f] = qual;
+        }
+        __syncthreads();  // T visible to the whole wave (cross-lane through LDS)
+
+        if (valid) {
+            // ---- stage 2: B[i][j] = sum_k T[i][k] * D[j][k], k ascending ------------
+            const int j = lane & 15, i0 = lane >> 4;
+            float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const float4 dv = *reinterpret_cast<const float4*>(&lds.D[j][4 * k4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 tv = *reinterpret_cast<const float4*>(&lds.T[wave][i0 + 4 * r][4 * k4]);
+                    b[r] = __fadd_rn(b[r], __fmul_rn(tv.x, dv.x));
+                    b[r] = __fadd_rn(b[r], __fmul_rn(tv.y, dv.y));
+                    b[r] = __fadd_rn(b[r], __fmul_rn(tv.z, dv.z));
+                    b[r] = __fadd_rn(b[r], __fmul_rn(tv.w, dv.w));
+                }
+            }
+
+            // ---- median: 128th smallest of the 256 coefficients (Torben's result) ---
+            uint32_t key[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t u = __float_as_uint(b[r]);
+                key[r] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving
+            }
+            uint32_t prefix = 0, mask = 0;
+            int kth = 128;
+#pragma unroll 1
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t bsel = 1u << bit;
+                const uint32_t m2 = mask | bsel;
+                int cnt0 = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cnt0 += __popcll(__ballot((key[r] & m2) == prefix));
+                if (kth > cnt0) {
+                    kth -= cnt0;
+                    prefix |= bsel;
+                }
+                mask = m2;
+            }
+            const uint32_t mu = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
+            const float med = __uint_as_float(mu);
+
+            // ---- bits: lane l, output r is coefficient (i0+4r, j) = bit l + 64 r ----
+            unsigned long long m[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = __ballot(b[r] > med);
+            if (lane < 4) {
+                const unsigned long long w = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+                reinterpret_cast<unsigned long long*>(hashes)[f * 4 + lane] = w;
+            }
+        }
+        __syncthreads();  // T is rewritten by the next trip
+    }
+}
+
+// rgb24 64x64 frames -> float luma (no blur: upstream's 64x64 shortcut).
+__global__ __launch_bounds__(256) void k_luma64_rgb(const uint8_t* __restrict__ rgb, long long npix,
+                                                    float* __restrict__ out) {
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        const float r = (float)rgb[3 * p], g = (float)rgb[3 * p + 1], b = (float)rgb[3 * p + 2];
+        float y = __fmul_rn(0.299f, r);
+        y = __fadd_rn(y, __fmul_rn(0.587f, g));
+        y = __fadd_rn(y, __fmul_rn(0.114f, b));
+        out[p] = y;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Down-sampler for frames that are not already 64x64 (the reference feeds 512x512
+// rgb24, vpdqpy/vpdqpy.py:90-95,113): luma, 2 x (box along rows, box along
+// columns) with upstream's sequential running-sum box filter, then decimation.
+//
+// The running sum makes every 1-D filter a *sequential* float recurrence, so the
+// parallelism is across lines, one lane per line. k_box_scan_T filters the lines
+// of a row-major [lines][len] image and writes the result TRANSPOSED ([len][lines]),
+// so that (a) the input is staged through an LDS ring with coalesced loads, (b) the
+// stores are coalesced across lanes, and (c) four launches of the same kernel give
+// rows, cols, rows, cols. Passes 3 and 4 only emit the 64 sample positions the
+// decimation keeps (the recurrence still runs over every element).
+constexpr int kTW = 32;           // columns per staged tile
+constexpr int kRing = 2 * kTW;    // LDS ring (window <= 32 looks back at most one tile)
+
+template <int SRC>  // 0: float, 1: gray u8, 3: rgb24 (luma fused into the load)
+__global__ __launch_bounds__(64) void k_box_scan_T(const void* __restrict__ in, float* __restrict__ out, int lines,
+                                                   int len, int win, int nsel, long long in_frame_stride,
+                                                   long long out_frame_stride) {
+    __shared__ float ring[64][kRing + 1];
+    const int lane = threadIdx.x;
+    const int line0 = blockIdx.x * 64;
+    const long long frame = blockIdx.y;
+    const int my_line = line0 + lane;
+    const int half = (win + 2) / 2;
+    const int steps = len + half - 1;
+    const int out_lines = lines;  // transposed output: [kept positions][lines]
+    float* dst = out + frame * out_frame_stride;
+
+    float sum = 0.0f;
+    int cur = 0;
+    int next_j = 0;
+    int next_sel = nsel ? (int)(((0 + 0.5) * len) / 64) : 0;
+
+    for (int s = 0; s < steps; ++s) {
+        if (s < len && (s % kTW) == 0) {
+            // stage columns [s, s+kTW) of the 64 lines into ring slot (s/kTW)&1
+            __syncthreads();
+            const int c = lane & (kTW - 1);
+            const int col = s + c;
+#pragma unroll 4
+            for (int rr = lane / kTW; rr < 64; rr += 64 / kTW) {
+                const int ln = line0 + rr;
+                float v = 0.0f;
+                if (ln < lines && col < len) {
+                    const long long e = (long long)ln * len + col;
+                    if (SRC == 0) {
+                        v = reinterpret_cast<const float*>(in)[frame * in_frame_stride + e];
+                    } else if (SRC == 1) {
+                        v = luma_gray(reinterpret_cast<const uint8_t*>(in)[frame * in_frame_stride + e]);
+                    } else {
+                        const uint8_t* p = reinterpret_cast<const uint8_t*>(in) + frame * in_frame_stride + 3 * e;
+                        const float r = (float)p[0], g = (float)p[1], b = (float)p[2];
+                        v = __fmul_rn(0.299f, r);
+                        v = __fadd_rn(v, __fmul_rn(0.587f, g));
+                        v = __fadd_rn(v, __fmul_rn(0.114f, b));
+                    }
+                }
+                ring[rr][col & (kRing - 1)] = v;
+            }
+            __syncthreads();
+        }
+        if (s < len) {
+            sum = __fadd_rn(sum, ring[lane][s & (kRing - 1)]);
+            if (s < win) ++cur;
+        }
+        if (s >= win) {
+            sum = __fsub_rn(sum, ring[lane][(s - win) & (kRing - 1)]);
+            if (s >= len) --cur;
+        }
+        if (s >= half - 1) {
+            const int oi = s - (half - 1);
+            bool keep = true;
+            int slot = oi;
+            if (nsel) {
+                keep = (next_j < nsel) && (oi == next_sel);
+                slot = next_j;
+            }
+            if (keep) {
+                float o;
+                if ((cur & (cur - 1)) == 0)
+                    o = __fmul_rn(sum, 1.0f / (float)cur);  // exact: power-of-two divisor
+                else
+                    o = __fdiv_rn(sum, (float)cur);
+                if (my_line < lines) dst[(long long)slot * out_lines + my_line] = o;
+                if (nsel) {
+                    ++next_j;
+                    next_sel = (int)(((next_j + 0.5) * len) / 64);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace hvd {
+
+hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
+                             int32_t* d_quality, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int64_t groups = (n + kWaves - 1) / kWaves;
+    const int64_t max_grid = 256 * 7;  // 7 workgroups/CU fit by LDS (21.8 KB each)
+    dim3 grid((unsigned)(groups < max_grid ? groups : max_grid));
+    if (kind == 0)
+        hipLaunchKernelGGL(k_pdq_hash64<0>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+    else
+        hipLaunchKernelGGL(k_pdq_hash64<1>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+    return hipGetLastError();
+}
+
+static int jarosz_window(int dim) { return (dim + 2 * 64 - 1) / (2 * 64); }
+
+// Workspace (floats per frame) the down-sampler needs besides the 64x64 output.
+size_t pdq_downsample_ws_floats(int h, int w) { return 2 * (size_t)h * w + (size_t)64 * h; }
+
+hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int w, int channels, float* d_ws,
+                                 float* d_out64, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (jarosz_window(h) > kTW || jarosz_window(w) > kTW) return hipErrorInvalidValue;
+    const size_t hw = (size_t)h * w;
+    const int win_rows = jarosz_window(w);  // window of the filter that runs along a row
+    const int win_cols = jarosz_window(h);
+    // Process frames in slabs so that the workspace stays bounded (y-grid limit too).
+    const int64_t slab = 1024;
+    for (int64_t f0 = 0; f0 < n; f0 += slab) {
+        const int64_t m = (n - f0) < slab ? (n - f0) : slab;
+        const size_t cnt = (size_t)(n < slab ? n : slab);  // frames the workspace is sized for
+        float* buf1 = d_ws;                   // [m][w][h]  pass-1 output (transposed)
+        float* buf2 = d_ws + cnt * hw;        // [m][h][w]  pass-2 output
+        float* buf3 = d_ws + 2 * cnt * hw;    // [m][64][h] pass-3 output
+        const uint8_t* src = d_frames + (size_t)f0 * hw * channels;
+        dim3 g1((h + 63) / 64, (unsigned)m), g2((w + 63) / 64, (unsigned)m), g4(1, (unsigned)m);
+        if (channels == 3)
+            hipLaunchKernelGGL(k_box_scan_T<3>, g1, dim3(64), 0, s, (const void*)src, buf1, h, w, win_rows, 0,
+                               (long long)hw * 3, (long long)hw);
+        else
+            hipLaunchKernelGGL(k_box_scan_T<1>, g1, dim3(64), 0, s, (const void*)src, buf1, h, w, win_rows, 0,
+                               (long long)hw, (long long)hw);
+        hipLaunchKernelGGL(k_box_scan_T<0>, g2, dim3(64), 0, s, (const void*)buf1, buf2, w, h, win_cols, 0,
+                           (long long)hw, (long long)hw);
+        hipLaunchKernelGGL(k_box_scan_T<0>, g1, dim3(64), 0, s, (const void*)buf2, buf3, h, w, win_rows, 64,
+                           (long long)hw, (long long)64 * h);
+        hipLaunchKernelGGL(k_box_scan_T<0>, g4, dim3(64), 0, s, (const void*)buf3, d_out64 + (size_t)f0 * 4096, 64, h,
+                           win_cols, 64, (long long)64 * h, (long long)4096);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_pdq_luma64_rgb(const uint8_t* d_frames, int64_t n, float* d_out64, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const long long npix = (long long)n * 4096;
+    long long blocks = (npix + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_luma64_rgb, dim3((unsigned)blocks), dim3(256), 0, s, d_frames, npix, d_out64);
+    return hipGetLastError();
+}
+
+}  // namespace hvd

@@ -1,0 +1,149 @@
+/*
+ * hvd_mi355x.h -- C-ABI of libhvd_mi355x.so: the MI355X (gfx950) replacement for the
+ * native module `hvdaccelerators.vpdq` that hydrus-video-deduplicator calls for its
+ * perceptual-hash hot path. Paths below are relative to the reference tree.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns
+ * HVD_OK (0) or a negative error code, never throws, and never keeps a caller
+ * pointer past the call. hvd_last_error() gives the message for the last failure on
+ * the calling thread. There is NO CPU fallback: without a usable gfx950 device
+ * hvd_init() fails with HVD_ERR_NO_DEVICE and every compute entry point fails with
+ * HVD_ERR_STATE.
+ *
+ * Layouts
+ *   frame hash  : 32 bytes = 256 bits; DCT coefficient bit k = i*16+j is byte k>>3,
+ *                 bit k&7 (little-endian image of PDQ's uint16 w[16];
+ *                 db/DedupeDB.py:535-559, dedup.py:83).
+ *   video hash  : concatenation of N>=0 frame hashes (dedup.py:77-86).
+ *   hvd_pair    : one frame-level hit (i<j, Hamming distance).
+ *   hvd_vmatch  : one video-level hit (a<b) with the vPDQ counters: q_hits = frames
+ *                 of a that have >=1 frame of b within max_dist, t_hits the converse.
+ */
+#ifndef HVD_MI355X_H
+#define HVD_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVD_OK 0
+#define HVD_ERR_ARG (-1)       /* bad argument */
+#define HVD_ERR_HIP (-2)       /* HIP runtime error */
+#define HVD_ERR_OVERFLOW (-3)  /* output buffer too small; *out_count holds the required size */
+#define HVD_ERR_NO_DEVICE (-4) /* no gfx950 device visible */
+#define HVD_ERR_RCCL (-5)      /* RCCL error */
+#define HVD_ERR_STATE (-6)     /* hvd_init() not called / comm not initialised */
+
+#define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
+#define HVD_UNIQUE_ID_BYTES 128
+#define HVD_ABI_VERSION 1
+
+typedef struct {
+    uint32_t i, j, dist, pad;
+} hvd_pair;
+
+typedef struct {
+    uint32_t a, b, q_hits, t_hits;
+} hvd_vmatch;
+
+/* ------------------------------------------------------------ lifecycle -- */
+
+int hvd_abi_version(void);
+/* Number of visible HIP devices (0 and HVD_OK when there is none). */
+int hvd_device_count(int* out_n);
+/* Bind this process to one GPU ("one process per GPU"), create the library stream,
+ * upload the 16x64 DCT matrix. Idempotent for the same device. */
+int hvd_init(int device);
+int hvd_shutdown(void);
+/* Copies the calling thread's last error message (NUL-terminated) into buf. */
+int hvd_last_error(char* buf, size_t len);
+/* The host-computed DCT matrix the kernels use (16*64 floats), for parity tests. */
+int hvd_dct_matrix(float* out_16x64);
+
+/* ------------------------------------------ host-buffer entry points ------ */
+/* These are what the Python `vpdq`-shaped shim binds; each stages through HBM,
+ * runs the HIP kernels on the library stream and copies results back. */
+
+/* Replaces the per-frame work of vpdq.VideoHasher.hash_frame (vpdqpy/vpdqpy.py:118)
+ * for a batch of pre-decoded frames. frames: n*h*w bytes (gray; luma is defined as
+ * the RGB formula with R=G=B) or n*h*w*3 bytes packed RGB24 row-major, exactly what
+ * bytes(frame.planes[0]) yields at vpdqpy.py:118. h,w >= 64. Outputs: n*32 hash
+ * bytes and n int32 qualities (0..100). Quality filtering (>=31 kept,
+ * db/DedupeDB.py:550-553) is the caller's job (VideoHasher.finish, vpdqpy.py:119). */
+int hvd_pdq_hash_frames_gray_u8(const uint8_t* frames, int64_t n, int h, int w, uint8_t* out_hashes,
+                                int32_t* out_quality);
+int hvd_pdq_hash_frames_rgb24_u8(const uint8_t* frames, int64_t n, int h, int w, uint8_t* out_hashes,
+                                 int32_t* out_quality);
+
+/* Replaces the O(visited nodes) stream of vpdq.matchHashBytes calls issued by the
+ * VP-tree (db/vptree.py:29-31,737; dedup.py:445-502) with one brute-force pass:
+ * all i<j with hamming(db[i],db[j]) <= max_dist and, when group != NULL,
+ * group[i] != group[j]. out receives min(count,cap) records sorted by (i,j);
+ * *out_count the true count (HVD_ERR_OVERFLOW if it exceeds cap). n < 2^32. */
+int hvd_allpairs_hamming256(const uint8_t* db, int64_t n, const int32_t* group, int max_dist, hvd_pair* out,
+                            int64_t cap, int64_t* out_count);
+
+/* Replaces one vpdq.matchHash / vpdq.matchHashBytes call (vpdqpy/vpdqpy.py:56,
+ * db/vptree.py:31): a, b are concatenated frame hashes (na, nb frames). Returns the
+ * two vPDQ counters; the percentage policy lives in the host shim. */
+int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, int max_dist, int32_t* q_hits,
+                  int32_t* t_hits);
+
+/* Replaces HydrusVideoDeduplicator.find_potential_duplicates' tree search
+ * (dedup.py:445-502) for a whole library: frames = all videos' frame hashes
+ * concatenated, offsets[V+1] = CSR boundaries in frames. out receives every video
+ * pair a<b with >=1 frame hit, sorted by (a,b). */
+int hvd_vpdq_match_videos(const uint8_t* frames, const int64_t* offsets, int64_t V, int max_dist, hvd_vmatch* out,
+                          int64_t cap, int64_t* out_count);
+
+/* --------------------------------------------- device-resident API ------- */
+/* For pipelines that keep data in HBM (hash on the GPU, then search) and for the
+ * benchmark. Pointers named d_* are device pointers from hvd_dev_malloc. Kernels are
+ * enqueued on the library stream and return immediately; hvd_dev_sync() waits. */
+
+int hvd_dev_malloc(void** out_ptr, size_t bytes);
+int hvd_dev_free(void* d_ptr);
+int hvd_dev_memset(void* d_ptr, int value, size_t bytes);
+int hvd_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
+int hvd_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
+int hvd_dev_sync(void);
+
+/* Bytes of device scratch hvd_dev_pdq_hash_frames needs for this geometry (0 for
+ * 64x64 gray): the 64x64 float luma of every frame plus the blur workspace. */
+int hvd_pdq_scratch_bytes(int64_t n, int h, int w, int channels, size_t* out_bytes);
+/* channels: 1 (gray u8) or 3 (RGB24). d_scratch: hvd_pdq_scratch_bytes() bytes
+ * (NULL when that is 0). h,w in [64,4096]. */
+int hvd_dev_pdq_hash_frames(const void* d_frames, int64_t n, int h, int w, int channels, void* d_scratch,
+                            void* d_hashes, void* d_quality);
+
+/* Brute-force pass over the tiles owned by `rank` of `world` (tile (rb,cb) belongs
+ * to rank (rb+cb) % world; world=1 => everything). Appends hvd_pair records to
+ * d_pairs[cap] and bumps the uint64 at d_count (the caller zeroes it). Records are
+ * unordered. variant: 0 = default kernel; see DESIGN.md for the others. */
+int hvd_dev_allpairs_hamming256(const void* d_db, int64_t n, const void* d_group, int max_dist, int rank, int world,
+                                void* d_pairs, int64_t cap, void* d_count, int variant);
+
+/* hipEvent pair on the library stream: wall time of everything enqueued between. */
+int hvd_timer_start(void);
+int hvd_timer_stop(float* out_ms);
+
+/* ----------------------------------------------- multi-GPU exchange ------ */
+/* One process per GPU; rank 0 creates the id, the launcher distributes it (bench.py
+ * uses torch.distributed's store for that), every rank calls hvd_comm_init. */
+int hvd_comm_unique_id(uint8_t out_id[HVD_UNIQUE_ID_BYTES]);
+int hvd_comm_init(const uint8_t id[HVD_UNIQUE_ID_BYTES], int rank, int world);
+/* RCCL all-gather over xGMI of each rank's candidate pairs: counts first, then the
+ * records padded to the max count. Every rank receives the concatenation (rank
+ * order) in out_host[cap]; *out_total is the total number of records. */
+int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_host, int64_t cap, int64_t* out_total);
+/* RCCL all-gather of equally sized device buffers (hash shards produced on-device). */
+int hvd_comm_allgather_bytes(const void* d_send, void* d_recv, size_t bytes_per_rank);
+int hvd_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVD_MI355X_H */

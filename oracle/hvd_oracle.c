@@ -1,0 +1,485 @@
+/*
+ * hvd_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT THE PRODUCT).
+ *
+ * Plain-C restatement of the arithmetic that hydrus-video-deduplicator delegates to
+ * the un-vendored third-party wheel `hvdaccelerators==0.4.0` (reference pyproject.toml:36,
+ * uv.lock:186-189), which wraps Meta ThreatExchange `pdq` + `vpdq` (docs/credits.md:7-9).
+ *
+ * PARITY UNPINNED: neither the wheel nor the reference's golden vectors (the
+ * tests/testdb git submodule, .gitmodules:1-3) exist in the build container, so
+ * this file restates the *published* PDQ / vPDQ algorithm (ThreatExchange
+ * pdq/cpp/hashing/pdqhashing.cpp, pdq/cpp/downscaling/downscaling.cpp,
+ * pdq/cpp/hashing/torben.cpp, vpdq/cpp/vpdq/cpp/matchTwoHash) and anchors on the
+ * reference's own call sites:
+ *   - VideoHasher.hash_frame(bytes(rgb24 plane))       vpdqpy/vpdqpy.py:113-119
+ *   - vpdq.matchHash(q, t, 31) / matchHashBytes(a,b,31) vpdqpy/vpdqpy.py:56, db/vptree.py:31
+ *   - 32 bytes per frame hash, little-endian w[0..15]   dedup.py:83, db/DedupeDB.py:535-559
+ *   - frames with quality < 31 are dropped               db/DedupeDB.py:550-553
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library. The product (libhvd_mi355x.so) never links or calls it.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math; no -march=native
+ * so the prebuilt .so also runs on the GPU box's host CPU).
+ *
+ * Floating-point contract (what "bit-exact" means for the GPU path):
+ *   every float op below is a separately rounded IEEE-754 binary32 op in the
+ *   written order (x86-64 baseline wheels have no FMA contraction); the DCT
+ *   matrix is computed in double and rounded once to float.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define HVD_OK 0
+#define HVD_ERR_ARG (-1)
+#define HVD_ERR_OVERFLOW (-3)
+
+typedef struct {
+    uint32_t i, j, dist, pad;
+} hvd_pair;
+
+typedef struct {
+    uint32_t a, b, q_hits, t_hits;
+} hvd_vmatch;
+
+/* ---------------------------------------------------------------- luma -- */
+
+/* pdqhashing.cpp fillFloatLumaFromRGB: float coefficients, left-to-right sum. */
+static const float kLumaR = 0.299f, kLumaG = 0.587f, kLumaB = 0.114f;
+
+void hvd_cpu_luma_rgb24(const uint8_t* rgb, int64_t npix, float* luma) {
+    for (int64_t p = 0; p < npix; ++p) {
+        float r = (float)rgb[3 * p + 0], g = (float)rgb[3 * p + 1], b = (float)rgb[3 * p + 2];
+        float y = kLumaR * r;
+        y = y + kLumaG * g;
+        y = y + kLumaB * b;
+        luma[p] = y;
+    }
+}
+
+/* Gray entry is *defined* as the RGB entry with R=G=B (SURVEY 7 "hard parts"),
+ * so VideoHasher.hash_frame(rgb with r=g=b) and the gray batch entry agree. */
+void hvd_cpu_luma_gray(const uint8_t* g, int64_t npix, float* luma) {
+    for (int64_t p = 0; p < npix; ++p) {
+        float v = (float)g[p];
+        float y = kLumaR * v;
+        y = y + kLumaG * v;
+        y = y + kLumaB * v;
+        luma[p] = y;
+    }
+}
+
+/* ------------------------------------------------------- Jarosz filter -- */
+
+/* downscaling.cpp computeJaroszFilterWindowSize(old, new=64). */
+static int jarosz_window(int old_dim) { return (old_dim + 2 * 64 - 1) / (2 * 64); }
+
+/* downscaling.cpp box1DFloat: sequential running sum, 4-phase edge schedule. */
+static void box1d(const float* in, float* out, int n, int stride, int w) {
+    int half = (w + 2) / 2;
+    int p1 = half - 1, p2 = w - half + 1, p3 = n - w, p4 = half - 1;
+    int li = 0, ri = 0, oi = 0;
+    float sum = 0.0f;
+    int cur = 0;
+    for (int i = 0; i < p1; ++i) {
+        sum += in[ri];
+        cur++;
+        ri += stride;
+    }
+    for (int i = 0; i < p2; ++i) {
+        sum += in[ri];
+        cur++;
+        out[oi] = sum / (float)cur;
+        ri += stride;
+        oi += stride;
+    }
+    for (int i = 0; i < p3; ++i) {
+        sum += in[ri];
+        sum -= in[li];
+        out[oi] = sum / (float)cur;
+        li += stride;
+        ri += stride;
+        oi += stride;
+    }
+    for (int i = 0; i < p4; ++i) {
+        sum -= in[li];
+        cur--;
+        out[oi] = sum / (float)cur;
+        li += stride;
+        oi += stride;
+    }
+}
+
+/* downscaling.cpp jaroszFilterFloat: nreps x (rows then cols); result ends in buf1. */
+static void jarosz(float* buf1, float* buf2, int h, int w, int win_rows, int win_cols, int nreps) {
+    for (int r = 0; r < nreps; ++r) {
+        for (int i = 0; i < h; ++i) box1d(buf1 + (size_t)i * w, buf2 + (size_t)i * w, w, 1, win_rows);
+        for (int j = 0; j < w; ++j) box1d(buf2 + j, buf1 + j, h, w, win_cols);
+    }
+}
+
+/* downscaling.cpp decimateFloat: sample pixel centres, double arithmetic. */
+static void decimate64(const float* in, int h, int w, float* out /*64*64*/) {
+    for (int i = 0; i < 64; ++i) {
+        int ini = (int)(((i + 0.5) * h) / 64);
+        for (int j = 0; j < 64; ++j) {
+            int inj = (int)(((j + 0.5) * w) / 64);
+            out[i * 64 + j] = in[(size_t)ini * w + inj];
+        }
+    }
+}
+
+/* --------------------------------------------------------- quality ------ */
+
+/* pdqhashing.cpp computePDQImageDomainQualityMetric. */
+static int quality64(const float* a /*64*64*/) {
+    int gsum = 0;
+    for (int i = 0; i < 63; ++i)
+        for (int j = 0; j < 64; ++j) {
+            float u = a[i * 64 + j], v = a[(i + 1) * 64 + j];
+            int d = (int)(((u - v) * 100.0f) / 255.0f);
+            gsum += abs(d);
+        }
+    for (int i = 0; i < 64; ++i)
+        for (int j = 0; j < 63; ++j) {
+            float u = a[i * 64 + j], v = a[i * 64 + j + 1];
+            int d = (int)(((u - v) * 100.0f) / 255.0f);
+            gsum += abs(d);
+        }
+    int q = gsum / 90;
+    return q > 100 ? 100 : q;
+}
+
+/* ------------------------------------------------------------- DCT ------ */
+
+static float g_dct[16 * 64];
+static pthread_once_t g_dct_once = PTHREAD_ONCE_INIT;
+
+/* pdqhashing.cpp fill_dct_matrix_64_cached: float scale * double cos, stored as float. */
+static void dct_init(void) {
+    const float scale = (float)sqrt(2.0 / 64.0);
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 64; ++j)
+            g_dct[i * 64 + j] = (float)((double)scale * cos((M_PI / 2 / 64.0) * (i + 1) * (2 * j + 1)));
+}
+
+const float* hvd_cpu_dct_matrix(void) {
+    pthread_once(&g_dct_once, dct_init);
+    return g_dct;
+}
+
+/* pdqhashing.cpp dct64To16: T = D*A (16x64), B = T*D^T (16x16); k-sequential
+ * mul-then-add, no contraction. */
+static void dct64to16(const float* A, float* T, float* B) {
+    const float* D = hvd_cpu_dct_matrix();
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 64; ++j) {
+            float s = 0.0f;
+            for (int k = 0; k < 64; ++k) {
+                float p = D[i * 64 + k] * A[k * 64 + j];
+                s = s + p;
+            }
+            T[i * 64 + j] = s;
+        }
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            float s = 0.0f;
+            for (int k = 0; k < 64; ++k) {
+                float p = T[i * 64 + k] * D[j * 64 + k];
+                s = s + p;
+            }
+            B[i * 16 + j] = s;
+        }
+}
+
+/* ---------------------------------------------------------- median ------ */
+
+/* torben.cpp (N. Devillard's public-domain Torben median), n = 256. */
+static float torben(const float* m, int n) {
+    int less, greater, equal;
+    float mn, mx, guess, maxlt, mingt;
+    mn = mx = m[0];
+    for (int i = 1; i < n; ++i) {
+        if (m[i] < mn) mn = m[i];
+        if (m[i] > mx) mx = m[i];
+    }
+    for (;;) {
+        guess = (mn + mx) / 2;
+        less = greater = equal = 0;
+        maxlt = mn;
+        mingt = mx;
+        for (int i = 0; i < n; ++i) {
+            if (m[i] < guess) {
+                less++;
+                if (m[i] > maxlt) maxlt = m[i];
+            } else if (m[i] > guess) {
+                greater++;
+                if (m[i] < mingt) mingt = m[i];
+            } else
+                equal++;
+        }
+        if (less <= (n + 1) / 2 && greater <= (n + 1) / 2) break;
+        if (less > greater)
+            mx = maxlt;
+        else
+            mn = mingt;
+    }
+    if (less >= (n + 1) / 2) return maxlt;
+    if (less + equal >= (n + 1) / 2) return guess;
+    return mingt;
+}
+
+/* pdqhashing.cpp pdqBuffer16x16ToBits + Hash256::setBit: bit k=i*16+j lives in
+ * uint16 word k>>4, bit k&15; the reference's BLOB is the little-endian image of
+ * w[0..15] (db/DedupeDB.py:538-544,553) => byte k>>3, bit k&7. */
+static void bits_from_dct(const float* B, uint8_t hash[32]) {
+    float med = torben(B, 256);
+    memset(hash, 0, 32);
+    for (int k = 0; k < 256; ++k)
+        if (B[k] > med) hash[k >> 3] |= (uint8_t)(1u << (k & 7));
+}
+
+/* ------------------------------------------------- one frame, from luma -- */
+
+/* pdqhashing.cpp pdqHash256FromFloatLuma. luma is clobbered; scratch has h*w floats.
+ * coeffs (nullable) receives the 16x16 DCT output for cross-implementation checks. */
+int hvd_cpu_pdq_from_luma(float* luma, float* scratch, int h, int w, uint8_t hash[32], int32_t* quality,
+                          float* coeffs) {
+    float a64[64 * 64], T[16 * 64], B[16 * 16];
+    if (h < 64 || w < 64) return HVD_ERR_ARG;
+    if (h == 64 && w == 64) {
+        memcpy(a64, luma, sizeof a64); /* upstream: already-downsampled video frames skip the blur */
+    } else {
+        jarosz(luma, scratch, h, w, jarosz_window(w), jarosz_window(h), 2);
+        decimate64(luma, h, w, a64);
+    }
+    *quality = quality64(a64);
+    dct64to16(a64, T, B);
+    bits_from_dct(B, hash);
+    if (coeffs) memcpy(coeffs, B, sizeof B);
+    return HVD_OK;
+}
+
+/* ------------------------------------------------------- frame batches -- */
+
+typedef struct {
+    const uint8_t* frames;
+    int64_t begin, end;
+    int h, w, channels;
+    uint8_t* hashes;
+    int32_t* quality;
+    float* coeffs;
+    int rc;
+} frame_job;
+
+static void* frame_worker(void* arg) {
+    frame_job* jb = (frame_job*)arg;
+    size_t npix = (size_t)jb->h * jb->w;
+    float* luma = (float*)malloc(npix * sizeof(float));
+    float* scratch = (float*)malloc(npix * sizeof(float));
+    jb->rc = HVD_OK;
+    for (int64_t f = jb->begin; f < jb->end; ++f) {
+        const uint8_t* src = jb->frames + (size_t)f * npix * jb->channels;
+        if (jb->channels == 3)
+            hvd_cpu_luma_rgb24(src, (int64_t)npix, luma);
+        else
+            hvd_cpu_luma_gray(src, (int64_t)npix, luma);
+        int rc = hvd_cpu_pdq_from_luma(luma, scratch, jb->h, jb->w, jb->hashes + 32 * f, jb->quality + f,
+                                       jb->coeffs ? jb->coeffs + 256 * f : NULL);
+        if (rc != HVD_OK) jb->rc = rc;
+    }
+    free(luma);
+    free(scratch);
+    return NULL;
+}
+
+static int hash_frames(const uint8_t* frames, int64_t n, int h, int w, int channels, uint8_t* hashes,
+                       int32_t* quality, float* coeffs, int num_threads) {
+    if (n < 0 || h < 64 || w < 64 || (n > 0 && (!frames || !hashes || !quality))) return HVD_ERR_ARG;
+    if (num_threads < 1) num_threads = 1;
+    if (num_threads > 256) num_threads = 256;
+    if ((int64_t)num_threads > n) num_threads = n > 0 ? (int)n : 1;
+    hvd_cpu_dct_matrix();
+    frame_job jobs[256];
+    pthread_t th[256];
+    int rc = HVD_OK;
+    for (int t = 0; t < num_threads; ++t) {
+        jobs[t] = (frame_job){frames, n * t / num_threads, n * (t + 1) / num_threads, h, w, channels,
+                              hashes, quality, coeffs, HVD_OK};
+        if (num_threads == 1)
+            frame_worker(&jobs[t]);
+        else
+            pthread_create(&th[t], NULL, frame_worker, &jobs[t]);
+    }
+    for (int t = 0; t < num_threads; ++t) {
+        if (num_threads > 1) pthread_join(th[t], NULL);
+        if (jobs[t].rc != HVD_OK) rc = jobs[t].rc;
+    }
+    return rc;
+}
+
+/* Counterpart of VideoHasher.hash_frame for a batch (vpdqpy/vpdqpy.py:118). */
+int hvd_cpu_pdq_hash_frames_gray_u8(const uint8_t* frames, int64_t n, int h, int w, uint8_t* out_hashes,
+                                    int32_t* out_quality, float* out_coeffs, int num_threads) {
+    return hash_frames(frames, n, h, w, 1, out_hashes, out_quality, out_coeffs, num_threads);
+}
+
+int hvd_cpu_pdq_hash_frames_rgb24_u8(const uint8_t* frames, int64_t n, int h, int w, uint8_t* out_hashes,
+                                     int32_t* out_quality, float* out_coeffs, int num_threads) {
+    return hash_frames(frames, n, h, w, 3, out_hashes, out_quality, out_coeffs, num_threads);
+}
+
+/* ------------------------------------------------------------- Hamming -- */
+
+/* pdq Hash256::hammingDistance: popcount of the XOR over 256 bits. */
+int hvd_cpu_hamming256(const uint8_t* a, const uint8_t* b) {
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+           __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+typedef struct {
+    const uint8_t* db;
+    const int32_t* group;
+    int64_t n, row_begin, row_end;
+    int max_dist;
+    hvd_pair* out; /* private buffer */
+    int64_t cap, count;
+} pair_job;
+
+static void* pair_worker(void* arg) {
+    pair_job* jb = (pair_job*)arg;
+    const uint64_t* d = (const uint64_t*)jb->db; /* db is 8-byte aligned by contract of the callers */
+    jb->count = 0;
+    for (int64_t i = jb->row_begin; i < jb->row_end; ++i) {
+        uint64_t a0 = d[4 * i], a1 = d[4 * i + 1], a2 = d[4 * i + 2], a3 = d[4 * i + 3];
+        for (int64_t j = i + 1; j < jb->n; ++j) {
+            int dist = __builtin_popcountll(a0 ^ d[4 * j]) + __builtin_popcountll(a1 ^ d[4 * j + 1]) +
+                       __builtin_popcountll(a2 ^ d[4 * j + 2]) + __builtin_popcountll(a3 ^ d[4 * j + 3]);
+            if (dist <= jb->max_dist) {
+                if (jb->group && jb->group[i] == jb->group[j]) continue;
+                if (jb->count < jb->cap) jb->out[jb->count] = (hvd_pair){(uint32_t)i, (uint32_t)j, (uint32_t)dist, 0};
+                jb->count++;
+            }
+        }
+    }
+    return NULL;
+}
+
+/* Brute-force ground truth of the pair predicate (finding 5):
+ * all i<j with hamming(db[i], db[j]) <= max_dist (and group[i] != group[j] when
+ * group is given). Output is sorted by (i, j). Rows [row_begin,row_end) only. */
+int hvd_cpu_allpairs_hamming256_rows(const uint8_t* db, int64_t n, const int32_t* group, int64_t row_begin,
+                                     int64_t row_end, int max_dist, hvd_pair* out, int64_t cap,
+                                     int64_t* out_count, int num_threads) {
+    if (n < 0 || !out_count || (n > 0 && !db) || row_begin < 0 || row_end > n || cap < 0) return HVD_ERR_ARG;
+    if (((uintptr_t)db & 7) != 0) return HVD_ERR_ARG;
+    if (num_threads < 1) num_threads = 1;
+    if (num_threads > 256) num_threads = 256;
+    int64_t rows = row_end > row_begin ? row_end - row_begin : 0;
+    if (rows == 0) {
+        *out_count = 0;
+        return HVD_OK;
+    }
+    if (num_threads > rows) num_threads = (int)rows;
+    pair_job jobs[256];
+    pthread_t th[256];
+    /* Split rows so that each thread gets ~equal triangle area. */
+    double total = 0;
+    for (int64_t i = row_begin; i < row_end; ++i) total += (double)(n - 1 - i);
+    int64_t r = row_begin;
+    double acc = 0;
+    for (int t = 0; t < num_threads; ++t) {
+        int64_t b = r;
+        double want = total * (t + 1) / num_threads;
+        while (r < row_end && (acc < want || t == num_threads - 1)) {
+            acc += (double)(n - 1 - r);
+            r++;
+        }
+        jobs[t] = (pair_job){db, group, n, b, r, max_dist, NULL, cap, 0};
+        jobs[t].out = (hvd_pair*)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(hvd_pair));
+        if (num_threads == 1)
+            pair_worker(&jobs[t]);
+        else
+            pthread_create(&th[t], NULL, pair_worker, &jobs[t]);
+    }
+    int64_t count = 0;
+    for (int t = 0; t < num_threads; ++t) {
+        if (num_threads > 1) pthread_join(th[t], NULL);
+        for (int64_t k = 0; k < jobs[t].count && k < jobs[t].cap; ++k) {
+            if (count + k < cap) out[count + k] = jobs[t].out[k];
+        }
+        count += jobs[t].count;
+        free(jobs[t].out);
+    }
+    *out_count = count;
+    return count > cap ? HVD_ERR_OVERFLOW : HVD_OK;
+}
+
+int hvd_cpu_allpairs_hamming256(const uint8_t* db, int64_t n, const int32_t* group, int max_dist, hvd_pair* out,
+                                int64_t cap, int64_t* out_count, int num_threads) {
+    return hvd_cpu_allpairs_hamming256_rows(db, n, group, 0, n, max_dist, out, cap, out_count, num_threads);
+}
+
+/* Count-only variant for the CPU baseline timing (no output traffic). */
+int64_t hvd_cpu_allpairs_count(const uint8_t* db, int64_t n, int max_dist, int num_threads) {
+    int64_t count = 0;
+    hvd_pair dummy;
+    hvd_cpu_allpairs_hamming256_rows(db, n, NULL, 0, n, max_dist, &dummy, 0, &count, num_threads);
+    return count;
+}
+
+/* ------------------------------------------------------- vPDQ matching -- */
+
+/* vpdq matchTwoHashBrute restated on raw 32-byte frame hashes: for each query
+ * frame, does ANY target frame lie within max_dist (comparator <=); and the
+ * symmetric count. The caller turns (q_hits, t_hits) into a percentage with a
+ * named policy (the reduction used by hvdaccelerators 0.4.0 is unpinned).
+ * Mirrors vpdq.matchHashBytes(a, b, tol) of db/vptree.py:31. */
+int hvd_cpu_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, int max_dist, int32_t* q_hits,
+                      int32_t* t_hits) {
+    if (na < 0 || nb < 0 || !q_hits || !t_hits) return HVD_ERR_ARG;
+    int32_t q = 0, t = 0;
+    for (int64_t i = 0; i < na; ++i)
+        for (int64_t j = 0; j < nb; ++j)
+            if (hvd_cpu_hamming256(a + 32 * i, b + 32 * j) <= max_dist) {
+                q++;
+                break;
+            }
+    for (int64_t j = 0; j < nb; ++j)
+        for (int64_t i = 0; i < na; ++i)
+            if (hvd_cpu_hamming256(a + 32 * i, b + 32 * j) <= max_dist) {
+                t++;
+                break;
+            }
+    *q_hits = q;
+    *t_hits = t;
+    return HVD_OK;
+}
+
+/* All video pairs a<b with at least one frame hit; frames is the concatenation of
+ * all videos' frame hashes, offsets[V+1] the CSR boundaries (in frames).
+ * Output sorted by (a, b). This is the brute-force ground truth that the
+ * reference's VP-tree search approximates (dedup.py:445-502, db/vptree.py:664-815). */
+int hvd_cpu_vpdq_match_videos(const uint8_t* frames, const int64_t* offsets, int64_t V, int max_dist,
+                              hvd_vmatch* out, int64_t cap, int64_t* out_count) {
+    if (V < 0 || !offsets || !out_count) return HVD_ERR_ARG;
+    int64_t count = 0;
+    for (int64_t a = 0; a < V; ++a)
+        for (int64_t b = a + 1; b < V; ++b) {
+            int32_t q, t;
+            hvd_cpu_match_two(frames + 32 * offsets[a], offsets[a + 1] - offsets[a], frames + 32 * offsets[b],
+                              offsets[b + 1] - offsets[b], max_dist, &q, &t);
+            if (q > 0 || t > 0) {
+                if (count < cap) out[count] = (hvd_vmatch){(uint32_t)a, (uint32_t)b, (uint32_t)q, (uint32_t)t};
+                count++;
+            }
+        }
+    *out_count = count;
+    return count > cap ? HVD_ERR_OVERFLOW : HVD_OK;
+}
