@@ -252,6 +252,13 @@ int hvd_dev_pdq_hash_frames(const void* d_frames, int64_t n, int h, int w, int c
     return HVD_OK;
 }
 
+int hvd_allpairs_tile_geometry(int64_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk) {
+    if (n < 0 || n >= (1ll << 32) || !rows_per_block || !col_chunk) return fail(HVD_ERR_ARG, "bad arguments");
+    if (!hvd::allpairs_geometry((uint32_t)n, variant, rows_per_block, col_chunk))
+        return fail(HVD_ERR_ARG, "unknown kernel variant %d", variant);
+    return HVD_OK;
+}
+
 int hvd_dev_allpairs_hamming256(const void* d_db, int64_t n, const void* d_group, int max_dist, int rank, int world,
                                 void* d_pairs, int64_t cap, void* d_count, int variant) {
     if (int rc = need_ready()) return rc;

@@ -22,6 +22,7 @@ struct AllPairsArgs {
 };
 
 hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s);
+bool allpairs_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 
 hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t max_dist,
                             uint32_t* d_tflags, int32_t* d_hits, hipStream_t s);

@@ -244,6 +244,28 @@ static hipError_t launch_allpairs_t(const AllPairsArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+static int variant_rows(int variant) {
+    switch (variant) {
+        case 0: case 1: case 5: case 6: return 4;
+        case 2: case 3: return 8;
+        case 4: return 2;
+        default: return 0;
+    }
+}
+
+// Tile geometry of a launch, exposed so that host code and tests can reproduce the
+// tile -> rank ownership rule ((rb + cb) % world) without a device.
+bool allpairs_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk) {
+    const int R = variant_rows(variant);
+    if (R == 0) return false;
+    const uint32_t rows = 256u * (uint32_t)R;
+    uint32_t chunk = pick_col_chunk(n, rows);
+    if ((n + chunk - 1) / chunk > 65535u) chunk = ((n + 65534u) / 65535u + 7u) & ~7u;
+    *rows_per_block = rows;
+    *col_chunk = chunk;
+    return true;
+}
+
 hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s) {
     if (a.n < 2) return hipSuccess;
     switch (a.variant) {

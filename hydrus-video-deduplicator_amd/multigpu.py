@@ -1,0 +1,160 @@
+"""All-pairs search sharded over the GPUs of one node: one process per GPU.
+
+The hash DB is replicated in every GPU's HBM (10 M hashes = 320 MB, nothing next to
+288 GB); the strict upper triangle of the pair matrix is cut into tiles and tile
+(rb, cb) belongs to rank (rb + cb) % world, which balances the triangle to within one
+tile per tile-row. There is no data-path collective while comparing; the single exchange
+step is an all-gather of each rank's candidate pairs (RCCL over xGMI, through the
+C-ABI), after which every rank holds the same sorted pair list.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PAIR_DTYPE
+
+
+def tile_geometry(n: int, variant: int = 0) -> tuple[int, int]:
+    """(rows_per_block, col_chunk) of the all-pairs launch for n hashes (host-only)."""
+    lib = _lib.load()
+    r, c = C.c_uint32(0), C.c_uint32(0)
+    _lib.check(lib.hvd_allpairs_tile_geometry(n, variant, C.byref(r), C.byref(c)))
+    return r.value, c.value
+
+
+def tile_owner(rb: int, cb: int, world: int) -> int:
+    """Ownership rule implemented by the kernel (k_hamming.hip)."""
+    return (rb + cb) % world
+
+
+def tiles_of_rank(n: int, rank: int, world: int, variant: int = 0):
+    """Yield (row0, row1, col0, col1) of the tiles rank owns that intersect the strict
+    upper triangle -- the host-side statement of the kernel's tile walk."""
+    rows, chunk = tile_geometry(n, variant)
+    n_rb = (n + rows - 1) // rows
+    n_cb = (n + chunk - 1) // chunk
+    for rb in range(n_rb):
+        row0 = rb * rows
+        for cb in range(n_cb):
+            col0, col1 = cb * chunk, min((cb + 1) * chunk, n)
+            if col1 <= row0 + 1:
+                continue
+            if tile_owner(rb, cb, world) != rank:
+                continue
+            yield row0, min(row0 + rows, n), col0, col1
+
+
+def merge_pairs(parts) -> np.ndarray:
+    """Concatenate per-rank records and sort by (i, j). Ranks own disjoint tiles, so there
+    are no duplicates to remove; this asserts it."""
+    parts = [np.asarray(p, dtype=PAIR_DTYPE) for p in parts]
+    allp = np.concatenate(parts) if parts else np.zeros(0, dtype=PAIR_DTYPE)
+    allp = allp[np.lexsort((allp["j"], allp["i"]))]
+    if allp.size > 1:
+        same = (allp["i"][1:] == allp["i"][:-1]) & (allp["j"][1:] == allp["j"][:-1])
+        if same.any():
+            raise AssertionError("a pair was reported by two ranks: tile ownership is not a partition")
+    return allp
+
+
+class RcclExchange:
+    """All-gather of candidate pairs through the library's RCCL communicator."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        self.rank, self.world = rank, world
+        lib = _lib.ensure()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(lib.hvd_comm_init(buf, rank, world))
+
+    @staticmethod
+    def create_unique_id() -> bytes:
+        lib = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        _lib.check(lib.hvd_comm_unique_id(buf))
+        return bytes(buf)
+
+    def allgather_pairs_dev(self, d_pairs_ptr: int, count: int) -> np.ndarray:
+        lib = _lib.ensure()
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, dtype=PAIR_DTYPE)
+            total = C.c_int64(0)
+            rc = lib.hvd_comm_allgather_pairs(d_pairs_ptr, count, out.ctypes.data, cap, C.byref(total))
+            if rc == _lib.HVD_ERR_OVERFLOW:
+                cap = int(total.value)
+                continue
+            _lib.check(rc)
+            return out[: total.value].copy()
+
+    def close(self) -> None:
+        _lib.check(_lib.load().hvd_comm_destroy())
+
+
+class TorchDistExchange:
+    """The same exchange over an existing torch.distributed process group (gloo on CPU):
+    used by the world_size-2 CPU tests and as the bootstrap channel for the RCCL id."""
+
+    def __init__(self):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def broadcast_bytes(self, data: bytes | None, nbytes: int, src: int = 0) -> bytes:
+        import torch
+
+        t = torch.zeros(nbytes, dtype=torch.uint8)
+        if self.rank == src:
+            t[:] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        self.dist.broadcast(t, src=src)
+        return bytes(t.numpy().tobytes())
+
+    def allgather_pairs(self, records: np.ndarray) -> np.ndarray:
+        import torch
+
+        records = np.ascontiguousarray(records, dtype=PAIR_DTYPE)
+        cnt = torch.tensor([records.size], dtype=torch.int64)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        self.dist.all_gather(counts, cnt)
+        counts = [int(c.item()) for c in counts]
+        mx = max(counts + [1])
+        send = torch.zeros(mx * 4, dtype=torch.int32)
+        if records.size:
+            send[: records.size * 4] = torch.from_numpy(records.view(np.int32).copy())
+        recv = [torch.zeros(mx * 4, dtype=torch.int32) for _ in range(self.world)]
+        self.dist.all_gather(recv, send)
+        parts = [r.numpy()[: c * 4].copy().view(PAIR_DTYPE) for r, c in zip(recv, counts)]
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=PAIR_DTYPE)
+
+
+def sharded_allpairs(d_db_ptr: int, n: int, rank: int, world: int, exchange: RcclExchange | None,
+                     max_dist: int = 31, d_group_ptr: int | None = None, variant: int = 0,
+                     cap: int = 1 << 20) -> np.ndarray:
+    """Run this rank's tiles on its GPU, exchange, return the full sorted pair list.
+    The DB (and group map) must already be resident in this rank's HBM."""
+    lib = _lib.ensure()
+    d_pairs = _lib.DeviceBuffer(16 * cap)
+    d_cnt = _lib.DeviceBuffer(8)
+    try:
+        while True:
+            d_cnt.zero()
+            _lib.check(lib.hvd_dev_allpairs_hamming256(d_db_ptr, n, d_group_ptr, max_dist, rank, world, d_pairs.ptr,
+                                                       cap, d_cnt.ptr, variant))
+            count = int(d_cnt.to_array(np.uint64, 1)[0])
+            if count <= cap:
+                break
+            cap = count  # overflow is reported, never truncated
+            d_pairs.free()
+            d_pairs = _lib.DeviceBuffer(16 * cap)
+        if world == 1 or exchange is None:
+            recs = d_pairs.to_array(PAIR_DTYPE, count)
+        else:
+            recs = exchange.allgather_pairs_dev(d_pairs.ptr, count)
+        return merge_pairs([recs])
+    finally:
+        d_pairs.free()
+        d_cnt.free()

@@ -1,0 +1,215 @@
+"""Drop-in for the native module ``hvdaccelerators.vpdq`` (PyPI hvdaccelerators==0.4.0),
+i.e. exactly the five names the reference imports from it:
+
+    vpdq.VideoHasher      vpdqpy/vpdqpy.py:113      VideoHasher(fps, w, h, num_threads)
+      .hash_frame(bytes)  vpdqpy/vpdqpy.py:118
+      .finish()->VpdqHash vpdqpy/vpdqpy.py:119
+    vpdq.VpdqHash         vpdqpy/vpdqpy.py:25       .bytes (dedup.py:77), bytesPerPdqHash
+                                                     (dedup.py:83), str() (hashing.py:30),
+                                                     from_string (hashing.py:40), len/==/!=
+                                                     (tests/unit_tests/test_vpdqpy.py:95,116)
+    vpdq.matchHash        vpdqpy/vpdqpy.py:56       matchHash(q, t, tol) -> float in [0,100]
+    vpdq.matchHashBytes   db/vptree.py:31           matchHashBytes(a, b, tol)
+
+All arithmetic runs in HIP kernels on an MI355X through the C-ABI of
+include/hvd_mi355x.h; there is no CPU fallback.
+
+Semantics that the (absent) wheel does not let us pin are explicit policies
+(SURVEY.md 3.5): the comparator is ``hamming <= tolerance`` and the reduction of the two
+vPDQ percentages (query-matched %, target-matched %) to one number is ``MATCH_POLICY``
+(default "min": the only symmetric choice, which dedup.py:502's ``// 2`` assumes).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+BYTES_PER_PDQ_HASH = 32
+QUALITY_TOLERANCE = 31  # frames with quality >= 31 are kept (db/DedupeDB.py:550-553)
+
+# "min" | "max" | "query" | "target"; see module docstring.
+MATCH_POLICY = os.environ.get("HVD_MATCH_POLICY", "min")
+_POLICIES = ("min", "max", "query", "target")
+
+
+def percent_from_hits(q_hits: int, t_hits: int, nq: int, nt: int, policy: str | None = None) -> float:
+    """vPDQ match percentage from the kernel's two counters (either side empty -> 0.0,
+    db/DedupeDB.py:555-557)."""
+    policy = MATCH_POLICY if policy is None else policy
+    if policy not in _POLICIES:
+        raise ValueError(f"unknown match policy {policy!r}; expected one of {_POLICIES}")
+    if nq <= 0 or nt <= 0:
+        return 0.0
+    qp = (q_hits * 100.0) / nq
+    tp = (t_hits * 100.0) / nt
+    if policy == "min":
+        return min(qp, tp)
+    if policy == "max":
+        return max(qp, tp)
+    return qp if policy == "query" else tp
+
+
+class VpdqHash:
+    """Immutable value: N concatenated 32-byte PDQ frame hashes (N >= 0)."""
+
+    bytesPerPdqHash = BYTES_PER_PDQ_HASH
+    __slots__ = ("_b",)
+
+    def __init__(self, data: bytes = b""):
+        data = bytes(data)
+        if len(data) % BYTES_PER_PDQ_HASH != 0:
+            raise ValueError(f"VpdqHash needs a multiple of {BYTES_PER_PDQ_HASH} bytes, got {len(data)}")
+        self._b = data
+
+    @property
+    def bytes(self) -> bytes:
+        return self._b
+
+    def __len__(self) -> int:
+        return len(self._b) // BYTES_PER_PDQ_HASH
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, VpdqHash) and self._b == other._b
+
+    def __ne__(self, other) -> bool:
+        return not self.__eq__(other)
+
+    def __hash__(self) -> int:
+        return hash(self._b)
+
+    def __str__(self) -> str:
+        # contiguous lowercase hex of .bytes, 64 chars per frame, single line
+        # (db/DedupeDB.py:547-559; tests read it back with readline(), test_benchmark_vpdqpy.py:58-59)
+        return self._b.hex()
+
+    def __repr__(self) -> str:
+        return f"VpdqHash(frames={len(self)})"
+
+    @staticmethod
+    def from_string(s: str) -> "VpdqHash":
+        s = s.strip()
+        if len(s) % (2 * BYTES_PER_PDQ_HASH) != 0:
+            raise ValueError("VpdqHash string must be 64 hex characters per frame")
+        try:
+            return VpdqHash(bytes.fromhex(s))
+        except ValueError as exc:
+            raise ValueError(f"invalid VpdqHash string: {exc}") from exc
+
+    def frames(self) -> np.ndarray:
+        """uint8[N,32] view of the frame hashes."""
+        return np.frombuffer(self._b, dtype=np.uint8).reshape(-1, BYTES_PER_PDQ_HASH)
+
+
+class VideoHasher:
+    """Per-video frame hasher. Frames are staged on the host and hashed in batches by the
+    PDQ kernel (the reference's hasher runs a CPU thread pool instead; ``num_threads`` is
+    accepted for signature compatibility and ignored). ``hash_frame`` applies
+    back-pressure by flushing a full batch synchronously, which bounds the staging memory
+    like the reference's blocking queue does (vpdqpy/vpdqpy.py:115-117)."""
+
+    def __init__(self, average_fps: int, width: int, height: int, num_threads: int = 0,
+                 batch_bytes: int = 256 << 20):
+        if width < 64 or height < 64:
+            raise ValueError("frames must be at least 64x64")
+        self.average_fps = average_fps
+        self.width = int(width)
+        self.height = int(height)
+        self.num_threads = num_threads
+        self._frame_bytes_rgb = self.width * self.height * 3
+        self._frame_bytes_gray = self.width * self.height
+        self._batch_frames = max(1, batch_bytes // self._frame_bytes_rgb)
+        self._pending: list[bytes] = []
+        self._pending_channels = 0
+        self._hashes: list[np.ndarray] = []
+        self._quality: list[np.ndarray] = []
+        self._finished = False
+        _lib.ensure()  # fail at construction, not at the first frame, if no GPU is usable
+
+    def hash_frame(self, frame) -> None:
+        """frame: packed RGB24 bytes (width*height*3, what bytes(frame.planes[0]) yields at
+        vpdqpy.py:118) or gray bytes (width*height)."""
+        if self._finished:
+            raise RuntimeError("hash_frame() after finish()")
+        mv = memoryview(frame)
+        n = mv.nbytes
+        if n == self._frame_bytes_rgb:
+            ch = 3
+        elif n == self._frame_bytes_gray:
+            ch = 1
+        else:
+            raise ValueError(f"frame has {n} bytes; expected {self._frame_bytes_rgb} (rgb24) or "
+                             f"{self._frame_bytes_gray} (gray)")
+        if self._pending and ch != self._pending_channels:
+            self._flush()
+        self._pending_channels = ch
+        self._pending.append(bytes(mv))
+        if len(self._pending) >= self._batch_frames:
+            self._flush()
+
+    def _flush(self) -> None:
+        if not self._pending:
+            return
+        ch = self._pending_channels
+        shape = (len(self._pending), self.height, self.width) + ((3,) if ch == 3 else ())
+        arr = np.frombuffer(b"".join(self._pending), dtype=np.uint8).reshape(shape)
+        self._pending = []
+        h, q = hash_frames(arr)
+        self._hashes.append(h)
+        self._quality.append(q)
+
+    def finish(self) -> VpdqHash:
+        self._flush()
+        self._finished = True
+        if not self._hashes:
+            return VpdqHash(b"")
+        h = np.concatenate(self._hashes)
+        q = np.concatenate(self._quality)
+        return VpdqHash(h[q >= QUALITY_TOLERANCE].tobytes())
+
+
+def hash_frames(frames: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Batch entry point: uint8[n,h,w] (gray) or uint8[n,h,w,3] (rgb24) ->
+    (hashes uint8[n,32], quality int32[n]). No quality filtering."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    lib = _lib.ensure()
+    if frames.ndim == 3:
+        fn = lib.hvd_pdq_hash_frames_gray_u8
+    elif frames.ndim == 4 and frames.shape[3] == 3:
+        fn = lib.hvd_pdq_hash_frames_rgb24_u8
+    else:
+        raise ValueError("frames must be uint8[n,h,w] or uint8[n,h,w,3]")
+    n, h, w = frames.shape[:3]
+    hashes = np.zeros((n, BYTES_PER_PDQ_HASH), dtype=np.uint8)
+    quality = np.zeros(n, dtype=np.int32)
+    _lib.check(fn(frames.ctypes.data, n, h, w, hashes.ctypes.data, quality.ctypes.data))
+    return hashes, quality
+
+
+def match_counts(a: bytes, b: bytes, distance_tolerance: int = 31) -> tuple[int, int]:
+    """(q_hits, t_hits) for query a / target b, both concatenated 32-byte frame hashes."""
+    a = bytes(a)
+    b = bytes(b)
+    if len(a) % BYTES_PER_PDQ_HASH or len(b) % BYTES_PER_PDQ_HASH:
+        raise ValueError("hash byte strings must be multiples of 32 bytes")
+    na, nb = len(a) // BYTES_PER_PDQ_HASH, len(b) // BYTES_PER_PDQ_HASH
+    lib = _lib.ensure()
+    q, t = C.c_int32(0), C.c_int32(0)
+    _lib.check(lib.hvd_match_two(a if na else None, na, b if nb else None, nb, int(distance_tolerance),
+                                 C.byref(q), C.byref(t)))
+    return q.value, t.value
+
+
+def matchHashBytes(a: bytes, b: bytes, distance_tolerance: int) -> float:
+    """db/vptree.py:31 call shape: similarity in [0,100] from two raw BLOBs."""
+    q, t = match_counts(a, b, distance_tolerance)
+    return percent_from_hits(q, t, len(a) // BYTES_PER_PDQ_HASH, len(b) // BYTES_PER_PDQ_HASH)
+
+
+def matchHash(query: VpdqHash, target: VpdqHash, distance_tolerance: int) -> float:
+    """vpdqpy/vpdqpy.py:56 call shape."""
+    return matchHashBytes(query.bytes, target.bytes, distance_tolerance)

@@ -1,0 +1,58 @@
+"""Host-side mirror of the reference facade ``vpdqpy/vpdqpy.py`` (class Vpdq), bound to the
+MI355X kernels instead of ``hvdaccelerators``. Same names, argument meaning and error
+behaviour; video *decoding* (PyAV/FFmpeg, vpdqpy.py:58-101) is out of scope, so
+``computeHash`` takes pre-decoded frames (or an iterable of frame byte strings) in the
+format ``frame_extract_pyav`` yields: 512x512 packed rgb24 (vpdqpy.py:90-95)."""
+
+from __future__ import annotations
+
+from collections.abc import Iterable
+
+import numpy as np
+
+from . import vpdq
+
+# The dimensions of the image after downscaling for pdq (vpdqpy.py:23)
+DOWNSCALE_DIMENSIONS = 512
+
+VpdqHash = vpdq.VpdqHash
+
+
+class Vpdq:
+    @staticmethod
+    def match_hash(query_features: VpdqHash, target_features: VpdqHash, distance_tolerance: float = 31.0):
+        """Get the similarity of two videos by comparing their list of features (vpdqpy.py:49-56)."""
+        return vpdq.matchHash(query_features, target_features, int(distance_tolerance))
+
+    @staticmethod
+    def computeHash(frames, num_threads: int = 0, width: int | None = None, height: int | None = None) -> VpdqHash:
+        """Perceptually hash a video given its decoded frames (vpdqpy.py:103-119 minus decode).
+
+        frames: uint8[n,h,w,3] / uint8[n,h,w] array, or an iterable of per-frame byte strings
+        (then width/height default to DOWNSCALE_DIMENSIONS, as the reference passes)."""
+        if frames is None:
+            raise ValueError
+        average_fps = 1  # timestamps are discarded (vpdqpy.py:110-112)
+        if isinstance(frames, np.ndarray):
+            if frames.ndim not in (3, 4):
+                raise ValueError("frames must be uint8[n,h,w] or uint8[n,h,w,3]")
+            h, w = frames.shape[1], frames.shape[2]
+            hasher = vpdq.VideoHasher(average_fps, w, h, num_threads)
+            flat = np.ascontiguousarray(frames, dtype=np.uint8).reshape(frames.shape[0], -1)
+            for f in flat:
+                hasher.hash_frame(f.data)
+            return hasher.finish()
+        if isinstance(frames, Iterable):
+            w = DOWNSCALE_DIMENSIONS if width is None else width
+            h = DOWNSCALE_DIMENSIONS if height is None else height
+            hasher = vpdq.VideoHasher(average_fps, w, h, num_threads)
+            for frame in frames:
+                hasher.hash_frame(frame)
+            return hasher.finish()
+        raise ValueError("Failed to hash: invalid frames object type.")
+
+    @staticmethod
+    def is_similar(vpdq_features1: VpdqHash, vpdq_features2: VpdqHash, threshold: float = 75.0) -> tuple[bool, float]:
+        """Threshold is minimum similarity to be considered similar (vpdqpy.py:121-131)."""
+        similarity = Vpdq.match_hash(query_features=vpdq_features1, target_features=vpdq_features2)
+        return similarity >= threshold, similarity

@@ -126,6 +126,10 @@ int hvd_dev_pdq_hash_frames(const void* d_frames, int64_t n, int h, int w, int c
 int hvd_dev_allpairs_hamming256(const void* d_db, int64_t n, const void* d_group, int max_dist, int rank, int world,
                                 void* d_pairs, int64_t cap, void* d_count, int variant);
 
+/* Host-only: the tile geometry hvd_dev_allpairs_hamming256 uses for (n, variant): a
+ * tile is rows [rb*rows_per_block, +rows_per_block) x columns [cb*col_chunk, +col_chunk). */
+int hvd_allpairs_tile_geometry(int64_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
+
 /* hipEvent pair on the library stream: wall time of everything enqueued between. */
 int hvd_timer_start(void);
 int hvd_timer_stop(float* out_ms);

@@ -1,0 +1,150 @@
+"""CPU tests: the C-ABI library loads and exports every declared symbol, fails loudly
+without a GPU (no CPU fallback), and the host-side logic mirrors the reference's
+semantics (VpdqHash value type, similarity policies, pair predicate)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hvd_mi355x.h")).read()
+    return sorted(set(re.findall(r"^\s*int\s+(hvd_\w+)\s*\(", text, flags=re.M)))
+
+
+def test_header_symbols_all_exported_and_bound(hvd):
+    from hvd_amd import _lib
+
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/hvd_mi355x.h but not exported"
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
+    assert lib.hvd_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback(hvd):
+    from hvd_amd import _lib
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible; the no-device path cannot be exercised here")
+    with pytest.raises(_lib.HvdError) as e:
+        _lib.init(0)
+    assert e.value.code == _lib.HVD_ERR_NO_DEVICE
+    with pytest.raises(_lib.HvdError):
+        hvd.vpdq.hash_frames(np.zeros((1, 64, 64), np.uint8))
+    with pytest.raises(_lib.HvdError):
+        hvd.matchHashBytes(b"\0" * 32, b"\0" * 32, 31)
+    with pytest.raises(_lib.HvdError):
+        hvd.allpairs_hamming(np.zeros((4, 32), np.uint8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "hydrus-video-deduplicator_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                src = open(path).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "libhvd_oracle" not in src, f
+            elif f.endswith((".cpp", ".hip", ".h", "Makefile")):
+                src = open(path).read()
+                assert "hvd_cpu_" not in src, f"{f} references an oracle symbol"
+                assert not re.search(r"#include\s+[\"<][^\">]*oracle", src), f
+
+
+def test_dct_matrix_host_copy_matches_oracle(hvd, oracle):
+    import ctypes as C
+
+    from hvd_amd import _lib
+
+    d = np.zeros((16, 64), np.float32)
+    _lib.check(_lib.load().hvd_dct_matrix(d.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(d.view(np.uint32), oracle.dct_matrix().view(np.uint32))
+
+
+def test_vpdqhash_value_semantics(hvd):
+    H = hvd.VpdqHash
+    assert H.bytesPerPdqHash == 32
+    a = H(bytes(range(32)) + bytes(range(32, 64)))
+    assert len(a) == 2 and a.bytes == bytes(range(64))
+    assert H.from_string(str(a)) == a and not (H.from_string(str(a)) != a)
+    assert str(a) == bytes(range(64)).hex() and "\n" not in str(a)
+    assert H.from_string(str(a) + "\n") == a  # tests read the text with file.read()/readline()
+    assert len(H(b"")) == 0 and str(H(b"")) == ""
+    assert a != H(bytes(64))
+    with pytest.raises(ValueError):
+        H(b"\0" * 31)
+    with pytest.raises(ValueError):
+        H.from_string("abc")
+    with pytest.raises(ValueError):
+        H.from_string("zz" * 32)
+    assert hvd.hashing.decode_phash_from_str(hvd.hashing.encode_phash_to_str(a)) == a
+
+
+def test_percent_policies(hvd):
+    p = hvd.vpdq.percent_from_hits
+    assert p(3, 1, 4, 2, "min") == 50.0
+    assert p(3, 1, 4, 2, "max") == 75.0
+    assert p(3, 1, 4, 2, "query") == 75.0
+    assert p(3, 1, 4, 2, "target") == 50.0
+    assert p(0, 0, 0, 5, "min") == 0.0 and p(0, 0, 5, 0, "max") == 0.0  # empty side => 0 (DedupeDB.py:555-557)
+    assert p(64, 64, 64, 64) == 100.0
+    with pytest.raises(ValueError):
+        p(1, 1, 1, 1, "median")
+
+
+def test_fix_vpdq_similarity_matches_reference_formula(hvd):
+    f = hvd.fix_vpdq_similarity
+    assert f(100.0) == 1 and f(0.0) == 101 and f(75.0) == 26 and f(74.99) == 27 and f(50) == 51
+
+
+def test_pair_predicate_int_sim_ge_int_threshold(hvd):
+    from hvd_amd._lib import VMATCH_DTYPE
+
+    recs = np.array([(0, 1, 32, 32), (0, 2, 31, 64), (1, 2, 64, 31), (2, 3, 1, 1)], dtype=VMATCH_DTYPE)
+    lengths = np.array([64, 64, 64, 64])
+    # 32/64 = 50.0 -> kept at threshold 50; 31/64 = 48.4 -> int 48 < 50
+    got = hvd.search.similar_video_pairs(recs, lengths, 50.0, "min")
+    assert got.tolist() == [[0, 1]]
+    got = hvd.search.similar_video_pairs(recs, lengths, 50.0, "max")
+    assert got.tolist() == [[0, 1], [0, 2], [1, 2]]
+    # truncation: threshold 48.9 -> int 48, and sim 48.4 -> int 48 => kept (reference: fix_vpdq_similarity)
+    got = hvd.search.similar_video_pairs(recs, lengths, 48.9, "min")
+    assert got.tolist() == [[0, 1], [0, 2], [1, 2]]
+    with pytest.raises(ValueError):
+        hvd.search.similar_video_pairs(recs, lengths, 0.5, "min")
+
+
+@pytest.mark.parametrize("n,world", [(5000, 2), (20000, 3), (70000, 8), (1025, 4), (2, 2)])
+def test_tile_ownership_partitions_the_upper_triangle(hvd, n, world):
+    from hvd_amd import multigpu as M
+
+    area = 0
+    per_rank = []
+    for r in range(world):
+        a = 0
+        for row0, row1, col0, col1 in M.tiles_of_rank(n, r, world):
+            # pairs (i,j) of this tile with i<j: count analytically
+            for_rows = np.arange(row0, row1)
+            lo = np.maximum(col0, for_rows + 1)
+            a += int(np.clip(col1 - lo, 0, None).sum())
+        per_rank.append(a)
+        area += a
+    assert area == n * (n - 1) // 2, "tiles of all ranks must cover every i<j pair exactly once"
+    if n >= 20000:
+        assert max(per_rank) <= 1.25 * (area / world), f"imbalanced: {per_rank}"
+
+
+def test_synth_is_deterministic(hvd):
+    a, pa = hvd.synth.hash_db(2000, seed=9, plant_fraction=0.01)
+    b, pb = hvd.synth.hash_db(2000, seed=9, plant_fraction=0.01)
+    assert np.array_equal(a, b) and np.array_equal(pa, pb)
+    f1 = hvd.synth.frames_gray(5, seed=4)
+    f2 = hvd.synth.frames_gray(5, seed=4)
+    assert np.array_equal(f1, f2) and f1.shape == (5, 64, 64)

@@ -1,0 +1,328 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP path, called through the
+C-ABI, against the CPU oracle on the same seeded inputs and against the committed golden
+fixtures. Bit-exact: hashes, qualities, pair lists and match counters are integers/bytes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ K1: PDQ hashing --
+
+def test_native_library_is_loaded_and_on_gfx950(gpu):
+    assert gpu.device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libhvd_mi355x.so" in maps
+
+
+def test_dct_matrix_on_box_matches_oracle(gpu, oracle):
+    d = np.zeros((16, 64), np.float32)
+    gpu.check(gpu.load().hvd_dct_matrix(d.ctypes.data))
+    assert np.array_equal(d.view(np.uint32), oracle.dct_matrix().view(np.uint32))
+
+
+def test_k1_golden_gray64(gpu, hvd):
+    g = load_golden("pdq_gray64.npz")
+    h, q = hvd.vpdq.hash_frames(g["frames"])
+    assert np.array_equal(h, g["hashes"])
+    assert np.array_equal(q, g["quality"])
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1023, 10000])
+def test_k1_gray64_vs_oracle(gpu, hvd, oracle, n):
+    """BASELINE config 2 at n=10000; ragged counts exercise the partial last workgroup."""
+    fr = hvd.synth.frames_gray(n, seed=2)
+    h, q = hvd.vpdq.hash_frames(fr)
+    ho, qo = oracle.hash_frames(fr, num_threads=8)
+    assert np.array_equal(q, qo), f"{int((q != qo).sum())} quality mismatches"
+    assert np.array_equal(h, ho), f"{int((h != ho).any(1).sum())} hash mismatches"
+
+
+def test_k1_gray64_extreme_frames(gpu, hvd, oracle):
+    rng = np.random.default_rng(11)
+    fr = np.stack([
+        np.zeros((64, 64), np.uint8), np.full((64, 64), 255, np.uint8),
+        rng.integers(0, 256, (64, 64), dtype=np.uint8),                 # white noise
+        (rng.integers(0, 2, (64, 64)) * 255).astype(np.uint8),          # binary noise, max gradients
+        np.tile(np.array([0, 255], np.uint8), (64, 32)),                # column stripes
+        np.tile(np.array([[0], [255]], np.uint8), (32, 64)),            # row stripes
+        np.tri(64, dtype=np.uint8) * 200,
+    ])
+    h, q = hvd.vpdq.hash_frames(fr)
+    ho, qo = oracle.hash_frames(fr)
+    assert np.array_equal(q, qo) and np.array_equal(h, ho)
+
+
+def test_k1_empty_batch(gpu, hvd):
+    h, q = hvd.vpdq.hash_frames(np.zeros((0, 64, 64), np.uint8))
+    assert h.shape == (0, 32) and q.shape == (0,)
+
+
+def test_k1_golden_rgb512_and_misc(gpu, hvd):
+    g = load_golden("pdq_rgb512.npz")
+    h, q = hvd.vpdq.hash_frames(g["frames"])
+    assert np.array_equal(h, g["hashes"]) and np.array_equal(q, g["quality"])
+    m = load_golden("pdq_rgb_misc.npz")
+    h, q = hvd.vpdq.hash_frames(m["frames_odd"])
+    assert np.array_equal(h, m["hashes_odd"]) and np.array_equal(q, m["quality_odd"])
+    h, q = hvd.vpdq.hash_frames(m["frames_64"])
+    assert np.array_equal(h, m["hashes_64"]) and np.array_equal(q, m["quality_64"])
+
+
+@pytest.mark.parametrize("shape", [(5, 512, 512, 3), (3, 64, 200, 3), (2, 257, 64, 3), (2, 130, 190)])
+def test_k1_downsampler_vs_oracle(gpu, hvd, oracle, shape):
+    n, h, w = shape[:3]
+    fr = hvd.synth.frames_rgb(n, seed=21, h=h, w=w) if len(shape) == 4 else hvd.synth.frames_gray(n, 22, h, w)
+    hh, q = hvd.vpdq.hash_frames(fr)
+    ho, qo = oracle.hash_frames(fr, num_threads=4)
+    assert np.array_equal(q, qo) and np.array_equal(hh, ho)
+
+
+def test_k1_bad_geometry_is_an_error(gpu, hvd):
+    with pytest.raises(gpu.HvdError):
+        hvd.vpdq.hash_frames(np.zeros((1, 32, 64), np.uint8))
+    with pytest.raises(ValueError):
+        hvd.vpdq.hash_frames(np.zeros((1, 64, 64, 4), np.uint8))
+
+
+def test_videohasher_dropin_surface(gpu, hvd, oracle):
+    """vpdqpy.py:113-119 call shape: VideoHasher(1, w, h, n).hash_frame(bytes)...finish()."""
+    fr = hvd.synth.frames_rgb(6, seed=31, h=512, w=512)
+    fr[2] = 40  # a flat frame: quality 0 -> dropped by finish()
+    hasher = hvd.VideoHasher(1, 512, 512, 4)
+    for f in fr:
+        hasher.hash_frame(bytes(f))
+    ph = hasher.finish()
+    ho, qo = oracle.hash_frames(fr, num_threads=4)
+    want = ho[qo >= 31].tobytes()
+    assert isinstance(ph, hvd.VpdqHash) and ph.bytes == want
+    assert len(ph.bytes) % hvd.VpdqHash.bytesPerPdqHash == 0 and len(ph) == int((qo >= 31).sum()) < 6
+    # facade: compute_phash on decoded frames, string round trip
+    ph2 = hvd.compute_phash(fr, num_threads=-2)
+    assert ph2 == ph and hvd.decode_phash_from_str(hvd.encode_phash_to_str(ph2)) == ph
+    # all frames low quality -> empty hash, legal (dedup.py:82)
+    e = hvd.compute_phash(np.full((3, 64, 64), 9, np.uint8))
+    assert len(e) == 0 and e.bytes == b""
+    with pytest.raises(ValueError):
+        hasher2 = hvd.VideoHasher(1, 64, 64, 0)
+        hasher2.hash_frame(b"\0" * 100)
+
+
+def test_gray_and_rgb_entries_agree(gpu, hvd):
+    g = hvd.synth.frames_gray(16, seed=33)
+    hg, qg = hvd.vpdq.hash_frames(g)
+    hr, qr = hvd.vpdq.hash_frames(np.repeat(g[..., None], 3, axis=3))
+    assert np.array_equal(hg, hr) and np.array_equal(qg, qr)
+
+
+# ------------------------------------------------------------ K2: all-pairs Hamming --
+
+def test_k2_golden(gpu, hvd):
+    g = load_golden("hamming_db.npz")
+    got = hvd.allpairs_hamming(g["db"], 31)
+    assert np.array_equal(got, g["pairs"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 255, 256, 257, 1024, 1025, 4097, 30000])
+def test_k2_vs_oracle_sizes(gpu, hvd, oracle, n):
+    db, _ = hvd.synth.hash_db(n, seed=40 + n % 7, plant_fraction=0.02)
+    got = hvd.allpairs_hamming(db, 31)
+    want = oracle.allpairs(db, 31, num_threads=8) if n else got[:0]
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("max_dist", [0, 1, 30, 31, 32, 100, 256])
+def test_k2_thresholds(gpu, hvd, oracle, max_dist):
+    db, _ = hvd.synth.hash_db(600, seed=50, plant_fraction=0.05)
+    got = hvd.allpairs_hamming(db, max_dist)
+    want = oracle.allpairs(db, max_dist, cap=600 * 600)
+    assert np.array_equal(got, want)
+    if max_dist == 256:
+        assert len(got) == 600 * 599 // 2
+
+
+def test_k2_duplicates_and_collisions(gpu, hvd, oracle):
+    db, _ = hvd.synth.hash_db(2000, seed=51, plant_fraction=0.0)
+    db[100:140] = db[7]          # 41 identical hashes -> 820 distance-0 pairs
+    db[1999] = ~db[0]            # distance 256
+    got = hvd.allpairs_hamming(db, 31)
+    assert np.array_equal(got, oracle.allpairs(db, 31))
+    assert int((got["dist"] == 0).sum()) == 41 * 40 // 2
+
+
+def test_k2_group_filter(gpu, hvd, oracle):
+    db, _ = hvd.synth.hash_db(5000, seed=52, plant_fraction=0.05)
+    grp = (np.arange(5000) // 3).astype(np.int32)
+    got = hvd.allpairs_hamming(db, 31, group=grp)
+    assert np.array_equal(got, oracle.allpairs(db, 31, group=grp, num_threads=8))
+
+
+def test_k2_overflow_is_reported_not_truncated(gpu, hvd):
+    db = np.zeros((300, 32), np.uint8)
+    out = np.zeros(10, gpu.PAIR_DTYPE)
+    cnt = C.c_int64(0)
+    rc = gpu.load().hvd_allpairs_hamming256(db.ctypes.data, 300, None, 31, out.ctypes.data, 10, C.byref(cnt))
+    assert rc == gpu.HVD_ERR_OVERFLOW and cnt.value == 300 * 299 // 2
+    assert "too small" in gpu.last_error()
+    assert len(hvd.allpairs_hamming(db, 31, cap=10)) == 300 * 299 // 2  # wrapper retries with the exact size
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
+    n = 20000
+    db, _ = hvd.synth.hash_db(n, seed=53, plant_fraction=0.01)
+    want = oracle.allpairs(db, 31, num_threads=8)
+    d_db = gpu.DeviceBuffer.from_array(db)
+    d_pairs = gpu.DeviceBuffer(16 * 4096)
+    d_cnt = gpu.DeviceBuffer(8)
+    d_cnt.zero()
+    gpu.check(gpu.load().hvd_dev_allpairs_hamming256(d_db.ptr, n, None, 31, 0, 1, d_pairs.ptr, 4096, d_cnt.ptr,
+                                                     variant))
+    cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+    got = hvd.multigpu.merge_pairs([d_pairs.to_array(gpu.PAIR_DTYPE, cnt)])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_k2_rank_sharding_on_one_gpu(gpu, hvd, oracle, world):
+    """Every rank's tile set run on this GPU in turn: the union must be the exact pair list
+    and the per-rank lists disjoint (merge_pairs asserts it)."""
+    n = 40000
+    db, _ = hvd.synth.hash_db(n, seed=54, plant_fraction=0.01)
+    d_db = gpu.DeviceBuffer.from_array(db)
+    parts = []
+    for r in range(world):
+        parts.append(hvd.multigpu.sharded_allpairs(d_db.ptr, n, r, world, None))
+    got = hvd.multigpu.merge_pairs(parts)
+    assert np.array_equal(got, oracle.allpairs(db, 31, num_threads=8))
+    assert min(len(p) for p in parts) > 0
+
+
+def test_k2_rccl_exchange_single_rank(gpu, hvd):
+    """world=1 communicator: exercises ncclCommInitRank + both all-gathers on the box."""
+    n = 5000
+    db, _ = hvd.synth.hash_db(n, seed=55, plant_fraction=0.02)
+    ex = hvd.multigpu.RcclExchange(0, 1, hvd.multigpu.RcclExchange.create_unique_id())
+    try:
+        d_db = gpu.DeviceBuffer.from_array(db)
+        d_pairs = gpu.DeviceBuffer(16 * 4096)
+        d_cnt = gpu.DeviceBuffer(8)
+        d_cnt.zero()
+        gpu.check(gpu.load().hvd_dev_allpairs_hamming256(d_db.ptr, n, None, 31, 0, 1, d_pairs.ptr, 4096, d_cnt.ptr, 0))
+        cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+        got = hvd.multigpu.merge_pairs([ex.allgather_pairs_dev(d_pairs.ptr, cnt)])
+        assert np.array_equal(got, hvd.allpairs_hamming(db, 31))
+        assert len(ex.allgather_pairs_dev(d_pairs.ptr, 0)) == 0
+    finally:
+        ex.close()
+
+
+def test_k2_full_size_1m_properties(gpu, hvd):
+    """BASELINE config 3 (1M hashes, ~5e11 comparisons): size-independent properties.
+    Planted pairs within tolerance must all be found with their exact distance; every
+    reported pair must verify on the host; nothing else is expected from uniform random
+    hashes (P(dist<=31) ~ 8e-38 per pair)."""
+    n = 1_000_000
+    db, planted = hvd.synth.hash_db(n, seed=3)
+    got = hvd.allpairs_hamming(db, 31)
+    x = np.unpackbits(db[got["i"]] ^ db[got["j"]], axis=1).sum(1)
+    assert np.array_equal(x, got["dist"]) and (got["dist"] <= 31).all() and (got["i"] < got["j"]).all()
+    found = set(zip(got["i"].tolist(), got["j"].tolist()))
+    d_pl = np.unpackbits(db[planted[:, 0]] ^ db[planted[:, 1]], axis=1).sum(1)
+    want = {(int(min(s, d)), int(max(s, d))) for (s, d, _), dd in zip(planted, d_pl) if dd <= 31}
+    assert want <= found
+    assert len(found) == len(got)  # no duplicates
+    # chains (copy of a copy) can add a few pairs beyond the directly planted ones, never many
+    assert len(found) - len(want) <= len(want) // 10 + 5
+
+
+# ----------------------------------------------------------- K3: video-level match --
+
+def test_match_two_vs_oracle(gpu, hvd, oracle):
+    g = load_golden("video_match.npz")
+    off, fb = g["offsets"], g["frames"]
+    rng = np.random.default_rng(60)
+    for _ in range(40):
+        a, b = rng.integers(0, len(off) - 1, 2)
+        ba, bb = fb[off[a]:off[a + 1]].tobytes(), fb[off[b]:off[b + 1]].tobytes()
+        assert hvd.vpdq.match_counts(ba, bb, 31) == oracle.match_two(ba, bb, 31)
+
+
+def test_match_hash_semantics(gpu, hvd):
+    g = load_golden("video_match.npz")
+    v = hvd.VpdqHash(g["frames"][:12].tobytes())
+    e = hvd.VpdqHash(b"")
+    assert hvd.matchHash(v, v, 31) == 100.0
+    assert hvd.Vpdq.is_similar(v, v) == (True, 100.0)
+    assert hvd.matchHash(v, e, 31) == 0.0 and hvd.matchHash(e, v, 31) == 0.0 and hvd.matchHash(e, e, 31) == 0.0
+    assert hvd.Vpdq.is_similar(e, e)[0] is False  # an empty hash is not even similar to itself (DedupeDB.py:555-557)
+    assert hvd.calculate_distance(v.bytes, v.bytes) == 1 and hvd.calculate_distance(v.bytes, b"") == 101
+    w = hvd.VpdqHash(g["frames"][:6].tobytes() + g["frames"][100:106].tobytes())
+    s = hvd.get_phash_similarity(v, w)
+    assert s == 50.0 and hvd.Vpdq.is_similar(v, w, threshold=50.0) == (True, 50.0)
+    assert hvd.Vpdq.is_similar(v, w)[0] is False  # default threshold 75
+    # large inputs: more frames than one workgroup pass
+    big = hvd.synth.video_hashes(2, seed=61, frames_per_video=700, copy_fraction=0.0)[0]
+    a, b = big[:700].tobytes(), big[350:1050].tobytes()
+    assert hvd.vpdq.match_counts(a, b, 31) == (350, 350)
+
+
+def test_k3_golden(gpu, hvd):
+    g = load_golden("video_match.npz")
+    got = hvd.match_videos(g["frames"], g["offsets"], 31)
+    assert np.array_equal(got, g["records"])
+
+
+@pytest.mark.parametrize("fpv", [1, 64, (0, 40), (50, 200)])
+def test_k3_vs_oracle(gpu, hvd, oracle, fpv):
+    V = 300 if fpv != (50, 200) else 80
+    frames, offsets, planted = hvd.synth.video_hashes(V, seed=62, frames_per_video=fpv, copy_fraction=0.1)
+    got = hvd.match_videos(frames, offsets, 31)
+    want = oracle.match_videos(frames, offsets, 31)
+    assert np.array_equal(got, want)
+    if fpv != (0, 40):
+        assert len(got) >= len(planted) > 0
+
+
+def test_find_potential_duplicates_pair_set(gpu, hvd, oracle):
+    """dedup.py:445-502 semantics: {A,B}: int(sim) >= int(threshold), from brute force."""
+    frames, offsets, planted = hvd.synth.video_hashes(200, seed=63, frames_per_video=(1, 64), copy_fraction=0.15)
+    blobs = [frames[offsets[v]:offsets[v + 1]].tobytes() for v in range(200)]
+    got = hvd.find_potential_duplicates([hvd.VpdqHash(b) for b in blobs], threshold=50.0)
+    want = []
+    for a in range(200):
+        for b in range(a + 1, 200):
+            q, t = oracle.match_two(blobs[a], blobs[b], 31)
+            sim = min(q * 100.0 / (len(blobs[a]) // 32), t * 100.0 / (len(blobs[b]) // 32))
+            if int(sim) >= 50:
+                want.append((a, b))
+    assert got == want and len(got) > 0
+    # every reported pair is confirmed by the legacy per-pair entry point, both directions
+    for a, b in got[:10]:
+        assert hvd.calculate_distance(blobs[a], blobs[b]) <= hvd.fix_vpdq_similarity(50.0)
+        assert hvd.calculate_distance(blobs[b], blobs[a]) <= hvd.fix_vpdq_similarity(50.0)
+
+
+def test_end_to_end_hash_then_search(gpu, hvd, oracle):
+    """BASELINE config 5 in miniature: videos of 64x64 frames -> hash on GPU -> video search;
+    near-copies (per-pixel noise +-2) must be found, and everything equals the oracle."""
+    rng = np.random.default_rng(64)
+    V, F = 40, 16
+    base = hvd.synth.frames_gray(V * F, seed=65, const_fraction=0.0).reshape(V, F, 64, 64)
+    copies = {5: 2, 17: 9, 30: 29}
+    for dst, src in copies.items():
+        noisy = base[src].astype(np.int16) + rng.integers(-2, 3, base[src].shape)
+        base[dst] = np.clip(noisy, 0, 255).astype(np.uint8)
+    phashes = [hvd.compute_phash(base[v]) for v in range(V)]
+    ho, qo = oracle.hash_frames(base.reshape(-1, 64, 64), num_threads=8)
+    for v in range(V):
+        sel = slice(v * F, (v + 1) * F)
+        assert phashes[v].bytes == ho[sel][qo[sel] >= 31].tobytes()
+    dup = hvd.find_potential_duplicates(phashes, threshold=50.0)
+    for dst, src in copies.items():
+        if len(phashes[dst]) and len(phashes[src]):
+            assert (min(src, dst), max(src, dst)) in dup

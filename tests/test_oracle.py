@@ -1,0 +1,169 @@
+"""CPU tests of the oracle itself: the C restatement against the independent numpy
+restatement, against the committed golden fixtures, and against analytic known answers.
+(The reference's own vectors are unavailable -- PARITY UNPINNED, oracle/hvd_oracle.c.)"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import pdq_numpy as P
+
+
+def test_dct_matrix_two_implementations(oracle):
+    assert np.array_equal(oracle.dct_matrix().view(np.uint32), P.dct_matrix().view(np.uint32))
+
+
+def test_dct_matrix_is_orthonormal_rows(oracle):
+    d = oracle.dct_matrix().astype(np.float64)
+    assert np.allclose(d @ d.T, np.eye(16), atol=1e-6)
+
+
+def test_golden_gray64(oracle):
+    g = load_golden("pdq_gray64.npz")
+    h, q, c = oracle.hash_frames(g["frames"], want_coeffs=True)
+    assert np.array_equal(h, g["hashes"])
+    assert np.array_equal(q, g["quality"])
+    assert np.array_equal(c.view(np.uint32), g["coeffs"].view(np.uint32))
+
+
+def test_golden_gray64_numpy_restatement():
+    g = load_golden("pdq_gray64.npz")
+    for f in range(0, len(g["frames"]), 3):
+        h, q, b = P.hash_gray(g["frames"][f])
+        assert h == g["hashes"][f].tobytes()
+        assert q == g["quality"][f]
+        assert np.array_equal(b.ravel().view(np.uint32), g["coeffs"][f].view(np.uint32))
+
+
+def test_golden_rgb512(oracle):
+    g = load_golden("pdq_rgb512.npz")
+    h, q, c = oracle.hash_frames(g["frames"], want_coeffs=True)
+    assert np.array_equal(h, g["hashes"]) and np.array_equal(q, g["quality"])
+    assert np.array_equal(c.view(np.uint32), g["coeffs"].view(np.uint32))
+    hh, qq, _ = P.hash_rgb(g["frames"][0])  # Jarosz path of the second implementation
+    assert hh == g["hashes"][0].tobytes() and qq == g["quality"][0]
+
+
+def test_golden_rgb_misc(oracle):
+    g = load_golden("pdq_rgb_misc.npz")
+    h, q = oracle.hash_frames(g["frames_odd"])
+    assert np.array_equal(h, g["hashes_odd"]) and np.array_equal(q, g["quality_odd"])
+    h, q = oracle.hash_frames(g["frames_64"])
+    assert np.array_equal(h, g["hashes_64"]) and np.array_equal(q, g["quality_64"])
+
+
+def test_threads_do_not_change_results(oracle):
+    g = load_golden("pdq_gray64.npz")
+    h1, q1 = oracle.hash_frames(g["frames"], num_threads=1)
+    h4, q4 = oracle.hash_frames(g["frames"], num_threads=4)
+    assert np.array_equal(h1, h4) and np.array_equal(q1, q4)
+
+
+def test_gray_entry_equals_rgb_entry_with_equal_channels(oracle):
+    g = load_golden("pdq_gray64.npz")["frames"][:8]
+    rgb = np.repeat(g[..., None], 3, axis=3)
+    hg, qg = oracle.hash_frames(g)
+    hr, qr = oracle.hash_frames(rgb)
+    assert np.array_equal(hg, hr) and np.array_equal(qg, qr)
+
+
+def test_constant_frame_has_quality_zero(oracle):
+    fr = np.stack([np.full((64, 64), v, np.uint8) for v in (0, 1, 77, 255)])
+    _, q = oracle.hash_frames(fr)
+    assert q.tolist() == [0, 0, 0, 0]
+
+
+def test_hash_has_128_bits_set_without_ties(oracle):
+    g = load_golden("pdq_gray64.npz")
+    c = g["coeffs"]
+    for f in range(len(c)):
+        if len(np.unique(c[f])) == 256:  # no ties => exactly the 128 largest are set
+            assert int(np.unpackbits(g["hashes"][f]).sum()) == 128
+
+
+def test_single_basis_image_sets_its_coefficient(oracle):
+    # frame = 128 + 100 * outer(D[p], D[q]) scaled: coefficient (p,q) must be the largest one
+    d = oracle.dct_matrix().astype(np.float64)
+    for p, q in [(0, 0), (3, 7), (15, 15), (9, 2)]:
+        img = 128 + 800 * np.outer(d[p], d[q])
+        fr = np.clip(np.rint(img), 0, 255).astype(np.uint8)[None]
+        _, _, c = oracle.hash_frames(fr, want_coeffs=True)
+        assert int(np.argmax(np.abs(c[0]))) == p * 16 + q
+        k = p * 16 + q
+        bit = (oracle.hash_frames(fr)[0][0][k >> 3] >> (k & 7)) & 1
+        assert bit == (1 if c[0][k] > 0 else 0)
+
+
+def test_bit_layout_byte_k_div_8_bit_k_mod_8(oracle):
+    g = load_golden("pdq_gray64.npz")
+    c, h = g["coeffs"][0], g["hashes"][0]
+    med = np.sort(c)[127]
+    for k in range(256):
+        assert ((h[k >> 3] >> (k & 7)) & 1) == (1 if c[k] > med else 0)
+
+
+def test_hamming_known_answers(oracle):
+    rng = np.random.default_rng(7)
+    x = rng.integers(0, 256, 32, dtype=np.uint8)
+    assert oracle.hamming256(x, x) == 0
+    assert oracle.hamming256(x, ~x) == 256
+    for k in range(256):  # every bit position, all byte/word boundaries
+        y = x.copy()
+        y[k >> 3] ^= 1 << (k & 7)
+        assert oracle.hamming256(x, y) == 1
+    for nflip in (31, 32):
+        y = x.copy()
+        for k in range(0, 8 * nflip, 8):
+            y[k >> 3] ^= 1
+        assert oracle.hamming256(x, y) == nflip
+        assert oracle.hamming256(x, y) == P.hamming(x.tobytes(), y.tobytes())
+
+
+def test_golden_allpairs(oracle):
+    g = load_golden("hamming_db.npz")
+    got = oracle.allpairs(g["db"], 31)
+    assert np.array_equal(got, g["pairs"])
+    # multi-threaded oracle and row-range form give the same list
+    assert np.array_equal(oracle.allpairs(g["db"], 31, num_threads=4), g["pairs"])
+    a = oracle.allpairs(g["db"], 31, rows=(0, 1500))
+    b = oracle.allpairs(g["db"], 31, rows=(1500, 3000))
+    assert np.array_equal(np.concatenate([a, b]), g["pairs"])
+
+
+def test_allpairs_boundary_31_vs_32(oracle):
+    g = load_golden("hamming_db.npz")
+    p31 = oracle.allpairs(g["db"], 31)
+    p32 = oracle.allpairs(g["db"], 32)
+    assert set(map(tuple, p31[["i", "j"]].tolist())) <= set(map(tuple, p32[["i", "j"]].tolist()))
+    assert (p31["dist"] <= 31).all() and (p32["dist"] <= 32).all()
+    extra = len(p32) - len(p31)
+    assert extra == int((p32["dist"] == 32).sum())
+
+
+def test_allpairs_group_filter(oracle):
+    g = load_golden("hamming_db.npz")
+    grp = (np.arange(len(g["db"])) // 7).astype(np.int32)
+    got = oracle.allpairs(g["db"], 31, group=grp)
+    want = g["pairs"][grp[g["pairs"]["i"]] != grp[g["pairs"]["j"]]]
+    assert np.array_equal(got, want)
+
+
+def test_golden_video_match(oracle):
+    g = load_golden("video_match.npz")
+    got = oracle.match_videos(g["frames"], g["offsets"], 31)
+    assert np.array_equal(got, g["records"])
+    # each record equals the pairwise matcher, and absent pairs have no hits
+    off = g["offsets"]
+    fb = g["frames"]
+    have = {(int(r["a"]), int(r["b"])): (int(r["q_hits"]), int(r["t_hits"])) for r in got}
+    for a in range(0, len(off) - 1, 5):
+        for b in range(a + 1, len(off) - 1, 3):
+            q, t = oracle.match_two(fb[off[a]:off[a + 1]].tobytes(), fb[off[b]:off[b + 1]].tobytes(), 31)
+            assert have.get((a, b), (0, 0)) == (q, t)
+
+
+def test_match_two_empty_and_self(oracle):
+    g = load_golden("video_match.npz")
+    v = g["frames"][:10].tobytes()
+    assert oracle.match_two(b"", v) == (0, 0)
+    assert oracle.match_two(v, b"") == (0, 0)
+    assert oracle.match_two(v, v) == (10, 10)
