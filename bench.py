@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the VPDQ hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one brute-force all-pairs pass (256-bit Hamming, tolerance 31) over a synthetic
+hash DB resident in HBM, including the candidate-pair exchange: BASELINE.json configs[2]
+(1M hashes, ~5e11 comparisons) at N=1. For N>1 the DB grows so that the comparisons per GPU
+stay fixed (weak scaling: n = 1M*sqrt(N)); the DB is replicated, tiles of the pair matrix
+are dealt round-robin to the ranks, the only collective is the RCCL all-gather of each
+rank's candidate pairs. The frame-hashing half of the metric (configs[1]: 10k pre-decoded
+64x64 frames) is measured in the same run and reported under "frames_hashed".
+
+Rank 0 prints ONE JSON line. The CPU baseline (the oracle, a port -- the reference's real
+arithmetic is the absent hvdaccelerators wheel) is timed on rank 0 at N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+BYTES_PER_COMPARISON = 64      # two 32-byte operands, no reuse credited
+BYTES_PER_FRAME_64 = 4096 + 32 + 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--hashes", type=int, default=1_000_000, help="DB size at N=1")
+    ap.add_argument("--frames", type=int, default=10_000)
+    ap.add_argument("--variant", type=int, default=-1, help="all-pairs kernel variant (-1: product default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import hvd_amd
+    from hvd_amd import _lib as L
+    from hvd_amd import multigpu as M
+    from hvd_amd import search, synth
+
+    lib = L.init(int(os.environ.get("HVD_FORCE_DEVICE", local_rank)))  # HVD_FORCE_DEVICE: dev testing only
+
+    dist = None
+    exchange = None
+    exchange_kind = "none"
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        boot = M.TorchDistExchange()
+        uid = boot.broadcast_bytes(M.RcclExchange.create_unique_id() if rank == 0 else None, 128, src=0)
+        try:
+            exchange = M.RcclExchange(rank, world, uid)
+            exchange_kind = "rccl"
+        except Exception as exc:  # reported in the JSON line, never silent
+            print(f"[bench] rank {rank}: RCCL init failed ({exc}); exchanging candidates over gloo", file=sys.stderr)
+            exchange = None
+            exchange_kind = "gloo-fallback"
+
+    def barrier():
+        L.check(lib.hvd_dev_sync())
+        if dist is not None:
+            dist.barrier()
+
+    variant = search.DEFAULT_VARIANT if args.variant < 0 else args.variant
+
+    # ---------------- workload: replicated synthetic hash DB ---------------------------
+    n = int(round(args.hashes * math.sqrt(world) / 1024.0)) * 1024 if world > 1 else args.hashes
+    db, planted = synth.hash_db(n, seed=3)
+    d_db = L.DeviceBuffer.from_array(db)
+    cap = 1 << 20
+    d_pairs = L.DeviceBuffer(16 * cap)
+    d_cnt = L.DeviceBuffer(8)
+    total_cmp = n * (n - 1) // 2
+
+    kernel_ms = []
+
+    def step(v=variant, timed=True):
+        d_cnt.zero()
+        L.check(lib.hvd_timer_start())
+        L.check(lib.hvd_dev_allpairs_hamming256(d_db.ptr, n, None, 31, rank, world, d_pairs.ptr, cap, d_cnt.ptr, v))
+        ms = C.c_float(0)
+        L.check(lib.hvd_timer_stop(C.byref(ms)))  # hipEvents on the library stream; also syncs
+        if timed:
+            kernel_ms.append(ms.value)
+        cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+        if cnt > cap:
+            raise RuntimeError("pair buffer overflow in bench")
+        if world == 1:
+            return d_pairs.to_array(L.PAIR_DTYPE, cnt)
+        if exchange is not None:
+            return exchange.allgather_pairs_dev(d_pairs.ptr, cnt)
+        return boot.allgather_pairs(d_pairs.to_array(L.PAIR_DTYPE, cnt))
+
+    for _ in range(args.warmup):
+        step(timed=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        km = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_avg_ms = float(km.item())
+    else:
+        kernel_avg_ms = float(np.mean(kernel_ms))
+
+    # parity gate that runs with every measurement: every planted pair within tolerance is
+    # reported with its exact distance, and every reported pair verifies on the host
+    merged = M.merge_pairs([recs])
+    dist_host = np.unpackbits(db[merged["i"]] ^ db[merged["j"]], axis=1).sum(1)
+    assert np.array_equal(dist_host, merged["dist"]) and (merged["dist"] <= 31).all()
+    d_pl = np.unpackbits(db[planted[:, 0]] ^ db[planted[:, 1]], axis=1).sum(1)
+    want = {(int(min(s, d)), int(max(s, d))) for (s, d, _), dd in zip(planted, d_pl) if dd <= 31}
+    assert want <= set(zip(merged["i"].tolist(), merged["j"].tolist())), "planted duplicate pair missed"
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_cmp / (elapsed / args.steps)
+
+    if rank != 0:
+        if exchange is not None:
+            exchange.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # kernel-level roofline (rank 0's share of the comparisons per launch)
+    cmp_per_launch = total_cmp / world
+    achieved = cmp_per_launch * BYTES_PER_COMPARISON / (kernel_avg_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"allpairs_n{n}_v{variant}_w{world}"
+            traffic = tj.get(key)
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": f"k_allpairs(variant={variant})", "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 3), "traffic": traffic,
+        "kernel_ms": round(kernel_avg_ms, 3),
+        "note": "algorithmic bytes = 64 B per comparison with no operand reuse credited (SURVEY.md 8d), so frac > 1 "
+                "means the tiles re-use operands from registers/SGPRs instead of HBM; the binding unit is the "
+                "integer VALU (v_bcnt_u32_b32 issues at half rate, profiles/r01_ubench_valu.txt)",
+    }
+
+    extra = {}
+    # full-popcount variant next to the default, for transparency (same DB, same launch shape)
+    if world == 1:
+        for v, name in ((0, "full_popcount_16op"), (1, "prefilter128_exact")):
+            ks = []
+            for r in range(3):
+                d_cnt.zero()
+                L.check(lib.hvd_timer_start())
+                L.check(lib.hvd_dev_allpairs_hamming256(d_db.ptr, n, None, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, v))
+                ms = C.c_float(0)
+                L.check(lib.hvd_timer_stop(C.byref(ms)))
+                if r:
+                    ks.append(ms.value)
+            extra[name] = {"kernel_ms": round(float(np.mean(ks)), 3),
+                           "comparisons_per_s": float(f"{total_cmp / (np.mean(ks) * 1e-3):.4g}")}
+
+    # ---------------- frames hashed / s (BASELINE configs[1]) --------------------------
+    frames_out = None
+    cpu = None
+    if world == 1:
+        fr = synth.frames_gray(args.frames, seed=2)
+        d_f = L.DeviceBuffer.from_array(fr)
+        d_h = L.DeviceBuffer(32 * args.frames)
+        d_q = L.DeviceBuffer(4 * args.frames)
+        reps = 20
+        L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, args.frames, 64, 64, 1, None, d_h.ptr, d_q.ptr))
+        L.check(lib.hvd_dev_sync())
+        L.check(lib.hvd_timer_start())
+        for _ in range(reps):
+            L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, args.frames, 64, 64, 1, None, d_h.ptr, d_q.ptr))
+        ms = C.c_float(0)
+        L.check(lib.hvd_timer_stop(C.byref(ms)))
+        k1_ms = ms.value / reps
+        fps = args.frames / (k1_ms * 1e-3)
+        frames_out = {
+            "workload": f"{args.frames} pre-decoded synthetic 64x64 gray frames -> PDQ hash + quality "
+                        "(BASELINE configs[1])",
+            "value": float(f"{fps:.4g}"), "unit": "frames/s", "kernel_ms": round(k1_ms, 4), "dtype": "f32",
+            "roofline": {"bound": "hbm", "kernel": "k_pdq_hash64", "achieved": round(fps * BYTES_PER_FRAME_64 / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(fps * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "fp32-VALU-bound at 64x64 (bit-exact non-FMA DCT: 2 VALU ops per MAC), not HBM-bound"},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O  # cpu_baseline leg only
+
+            cores = os.cpu_count() or 1
+            # bounded sample of the same workload: calibrate, then ~cpu-seconds of work
+            n0 = 40_000
+            t = time.perf_counter()
+            O.allpairs_count(db[:n0], 31, num_threads=cores)
+            rate = (n0 * (n0 - 1) / 2) / (time.perf_counter() - t)
+            ns = int(min(n, max(n0, math.sqrt(2 * rate * args.cpu_seconds))))
+            t = time.perf_counter()
+            O.allpairs_count(db[:ns], 31, num_threads=cores)
+            dt = time.perf_counter() - t
+            cpu_cmp = ns * (ns - 1) / 2 / dt
+            t = time.perf_counter()
+            ho, qo = O.hash_frames(fr, num_threads=cores)
+            dtf = time.perf_counter() - t
+            hg = d_h.to_array(np.uint8, 32 * args.frames).reshape(-1, 32)
+            qg = d_q.to_array(np.int32, args.frames)
+            assert np.array_equal(hg, ho) and np.array_equal(qg, qo), "GPU frame hashes differ from the oracle"
+            cpu = {"value": float(f"{cpu_cmp:.4g}"), "unit": "comparisons/s", "cores": cores, "kind": "port",
+                   "sample": f"oracle (C, popcnt, pthreads) all-pairs over the first {ns} of the {n} hashes "
+                             f"({ns * (ns - 1) // 2:.3g} comparisons, {dt:.1f} s)",
+                   "frames_per_s": float(f"{args.frames / dtf:.4g}"),
+                   "frames_sample": f"oracle PDQ over the same {args.frames} frames, {cores} threads, {dtf:.2f} s",
+                   "note": "the reference's real CPU path (hvdaccelerators 0.4.0) is not installable offline; this "
+                           "is the oracle port"}
+
+    out = {
+        "metric": "hash-pair comparisons/sec", "value": float(f"{value:.5g}"), "unit": "comparisons/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"all-pairs 256-bit Hamming (tolerance 31) over {n} synthetic hashes with planted "
+                               f"near-duplicates, {total_cmp:.6g} comparisons per step"
+                               + (" (BASELINE configs[2])" if world == 1 and n == 1_000_000 else
+                                  f" (configs[2] scaled weakly: n = 1M*sqrt({world}))"),
+                   "n_hashes": n, "max_dist": 31, "kernel_variant": variant,
+                   "parallelism": f"tile-cyclic x{world}, DB replicated, exchange={exchange_kind}",
+                   "pairs_found": int(len(merged))},
+        "roofline": roofline,
+    }
+    if extra:
+        out["kernel_variants"] = extra
+    if frames_out:
+        out["frames_hashed"] = frames_out
+    if cpu:
+        out["cpu_baseline"] = cpu
+    print(json.dumps(out))
+    if exchange is not None:
+        exchange.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

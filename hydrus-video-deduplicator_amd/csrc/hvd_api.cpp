@@ -344,7 +344,7 @@ static int allpairs_host_raw(const uint8_t* db, int64_t n, const int32_t* group,
     HIP_TRY(d_cnt.alloc(8));
     HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 8, g.stream));
     if (int rc = hvd_dev_allpairs_hamming256(d_db.p, n, group ? d_grp.p : nullptr, max_dist, 0, 1, d_pairs.p, cap,
-                                             d_cnt.p, 0))
+                                             d_cnt.p, HVD_DEFAULT_VARIANT))
         return rc;
     unsigned long long cnt = 0;
     HIP_TRY(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, g.stream));
