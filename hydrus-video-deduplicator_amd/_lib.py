@@ -49,6 +49,9 @@ SIGNATURES = {
     "hvd_pdq_scratch_bytes": (_int, [_i64, _int, _int, _int, C.POINTER(_sz)]),
     "hvd_dev_pdq_hash_frames": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "hvd_dev_allpairs_hamming256": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _i64, _vp, _int]),
+    "hvd_fp4_image_bytes": (_int, [_i64, C.POINTER(_sz)]),
+    "hvd_dev_expand_fp4": (_int, [_vp, _i64, _vp]),
+    "hvd_dev_allpairs_hamming256_mfma": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _i64, _vp, _int]),
     "hvd_allpairs_tile_geometry": (_int, [_i64, _int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "hvd_timer_start": (_int, []),
     "hvd_timer_stop": (_int, [C.POINTER(C.c_float)]),

@@ -254,8 +254,48 @@ int hvd_dev_pdq_hash_frames(const void* d_frames, int64_t n, int h, int w, int c
 
 int hvd_allpairs_tile_geometry(int64_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk) {
     if (n < 0 || n >= (1ll << 32) || !rows_per_block || !col_chunk) return fail(HVD_ERR_ARG, "bad arguments");
-    if (!hvd::allpairs_geometry((uint32_t)n, variant, rows_per_block, col_chunk))
+    if (!hvd::allpairs_geometry((uint32_t)n, variant, rows_per_block, col_chunk) &&
+        !hvd::allpairs_mfma_geometry((uint32_t)n, variant, rows_per_block, col_chunk))
         return fail(HVD_ERR_ARG, "unknown kernel variant %d", variant);
+    return HVD_OK;
+}
+
+int hvd_fp4_image_bytes(int64_t n, size_t* out_bytes) {
+    if (n < 0 || n >= (1ll << 32) || !out_bytes) return fail(HVD_ERR_ARG, "bad arguments");
+    *out_bytes = (size_t)hvd::fp4_rows_padded((uint32_t)n) * 128u;
+    return HVD_OK;
+}
+
+int hvd_dev_expand_fp4(const void* d_db, int64_t n, void* d_img) {
+    if (int rc = need_ready()) return rc;
+    if (n < 0 || n >= (1ll << 32) || !d_img || (n > 0 && !d_db)) return fail(HVD_ERR_ARG, "bad arguments");
+    HIP_TRY(hvd::launch_expand_fp4(d_db, (uint32_t)n, d_img, g.stream));
+    return HVD_OK;
+}
+
+int hvd_dev_allpairs_hamming256_mfma(const void* d_db, const void* d_img, int64_t n, const void* d_group, int max_dist, int rank,
+                                     int world, void* d_pairs, int64_t cap, void* d_count, int variant) {
+    if (int rc = need_ready()) return rc;
+    if (n < 0 || n >= (1ll << 32)) return fail(HVD_ERR_ARG, "n=%lld out of range [0,2^32)", (long long)n);
+    if (max_dist < 0 || max_dist > 256) return fail(HVD_ERR_ARG, "max_dist=%d out of range [0,256]", max_dist);
+    if (world < 1 || rank < 0 || rank >= world) return fail(HVD_ERR_ARG, "bad rank/world %d/%d", rank, world);
+    if (cap < 0 || !d_count || (cap > 0 && !d_pairs)) return fail(HVD_ERR_ARG, "bad output buffer");
+    if (n < 2) return HVD_OK;
+    if (!d_img || !d_db) return fail(HVD_ERR_ARG, "d_db / d_img is NULL");
+    hvd::AllPairsArgs a;
+    a.d_db = d_db;
+    a.n = (uint32_t)n;
+    a.d_group = (const int32_t*)d_group;
+    a.max_dist = (uint32_t)max_dist;
+    a.rank = (uint32_t)rank;
+    a.world = (uint32_t)world;
+    a.d_pairs = (hvd_pair*)d_pairs;
+    a.cap = (unsigned long long)cap;
+    a.d_count = (unsigned long long*)d_count;
+    a.variant = variant;
+    a.col_chunk = 0;
+    hipError_t e = hvd::launch_allpairs_mfma(a, d_img, g.stream);
+    if (e != hipSuccess) return fail(HVD_ERR_HIP, "launch_allpairs_mfma(variant=%d): %s", variant, hipGetErrorString(e));
     return HVD_OK;
 }
 

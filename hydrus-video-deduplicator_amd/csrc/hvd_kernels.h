@@ -24,6 +24,12 @@ struct AllPairsArgs {
 hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s);
 bool allpairs_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 
+// FP4-MFMA form (k_hamming_mfma.hip), variants 8..11. d_img: fp4_rows_padded(n)*128 bytes.
+uint32_t fp4_rows_padded(uint32_t n);
+hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s);
+hipError_t launch_allpairs_mfma(const AllPairsArgs& a, const void* d_img, hipStream_t s);
+bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
+
 hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t max_dist,
                             uint32_t* d_tflags, int32_t* d_hits, hipStream_t s);
 

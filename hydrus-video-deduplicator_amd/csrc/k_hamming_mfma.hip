@@ -1,0 +1,304 @@
+// k_hamming_mfma.hip -- all-pairs 256-bit Hamming on the gfx950 matrix cores.
+//
+// Same contract as k_allpairs (k_hamming.hip): all i<j with hamming(db[i],db[j]) <=
+// max_dist, bit-identical pair set. The brute-force pair matrix IS a matrix product once
+// every hash bit b is written as the number 1-2b in {+1,-1}:
+//      dot(a,b) = sum_k a_k*b_k = 256 - 2*hamming(a,b)
+// +-1 are exactly representable in FP4 (e2m1: 0x2 = +1.0, 0xA = -1.0), products are +-1
+// and the fp32 accumulation of 256 of them is exact, so thresholding the MFMA output at
+// dot >= 256 - 2*max_dist is the same predicate as the popcount kernel's, and the distance
+// of a hit is recovered as (256 - dot)/2. v_mfma_f32_32x32x64_f8f6f4 (cbsz=blgp=4) does a
+// 32x32 block of comparisons over 64 bits in one instruction (32 cycles/SIMD), against
+// 16 half-rate VALU ops per comparison for the popcount form.
+//
+// Data: k_expand_fp4 writes the "FP4 image" of the DB once: 128 B per hash = 8 chunks of
+// 16 B (chunk c = bits 32c..32c+31 as 32 nibbles); chunk c of hash n lives in slot
+// c ^ ((n>>1)&7) so that a wave's ds_read_b128 of one chunk of 32 consecutive hashes is
+// bank-conflict free. An MFMA operand for k-step s is chunk 2s+(lane>>5) of hash
+// (lane&31): A and B use the same element order, so the pairing of k indices inside the
+// instruction is irrelevant.
+//
+// Kernel: workgroup = 4 waves; wave w keeps TILES x 32 query hashes as A fragments in
+// VGPRs for the whole tile (TILES*16 VGPRs); candidates stream through LDS in
+// super-panels of 128 hashes (16 KB, double buffered, one barrier per super-panel). For
+// each 32-candidate panel and each query tile: 2 (PREFILTER: first 128 bits) or 4 MFMAs,
+// a 16-register max tree, and one wave-uniform branch per panel into the rare path that
+// recomputes the full distance and appends the pairs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvd_kernels.h"
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v16f mfma_fp4(v4i a, v4i b, v16f c) {
+    const v8i xa = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+    const v8i xb = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    // cbsz = blgp = 4: both operands FP4 e2m1; scale 0 -> the unscaled instruction
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, xb, c, 4, 4, 0, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t img_slot(uint32_t hash, uint32_t chunk) { return chunk ^ ((hash >> 1) & 7u); }
+
+// One thread per (hash, chunk). Rows >= n (padding up to n_pad) become FP4 zeros.
+__global__ __launch_bounds__(256) void k_expand_fp4(const uint32_t* __restrict__ db, uint32_t n, uint32_t n_pad,
+                                                    uint4* __restrict__ img) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (uint64_t)n_pad * 8u) return;
+    const uint32_t hash = (uint32_t)(idx >> 3), chunk = (uint32_t)(idx & 7u);
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
+    if (hash < n) {
+        const uint32_t w = db[(size_t)hash * 8u + chunk];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t x = 0x22222222u;  // +1.0 in every nibble
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x |= ((w >> (8 * d + t)) & 1u) << (4 * t + 3);  // bit set -> sign -> -1.0
+            o[d] = x;
+        }
+    }
+    img[(size_t)hash * 8u + img_slot(hash, chunk)] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// Max of the 16 accumulator registers, taken on the BIT PATTERNS as signed integers:
+// for a positive threshold, "float >= thr" and "bits >= thr_bits" agree (negative floats
+// have the sign bit set and compare below every positive pattern), and v_max3_i32 needs no
+// NaN canonicalisation. (The host routes max_dist >= 128, where thr <= 0, to the popcount
+// kernel.)
+__device__ __forceinline__ int max16_bits(const v16f& c) {
+    int m0 = max(max(__float_as_int(c[0]), __float_as_int(c[1])), __float_as_int(c[2]));
+    int m1 = max(max(__float_as_int(c[3]), __float_as_int(c[4])), __float_as_int(c[5]));
+    int m2 = max(max(__float_as_int(c[6]), __float_as_int(c[7])), __float_as_int(c[8]));
+    int m3 = max(max(__float_as_int(c[9]), __float_as_int(c[10])), __float_as_int(c[11]));
+    int m4 = max(max(__float_as_int(c[12]), __float_as_int(c[13])), __float_as_int(c[14]));
+    m0 = max(max(m0, m1), m2);
+    m3 = max(max(m3, m4), __float_as_int(c[15]));
+    return max(m0, m3);
+}
+
+__device__ __forceinline__ void append_pair_m(hvd_pair* out, unsigned long long cap, unsigned long long* count,
+                                              uint32_t i, uint32_t j, uint32_t dist) {
+    unsigned long long slot = atomicAdd(count, 1ull);
+    if (slot < cap) {
+        hvd_pair p;
+        p.i = i;
+        p.j = j;
+        p.dist = dist;
+        p.pad = 0;
+        out[slot] = p;
+    }
+}
+
+constexpr int kSuper = 128;  // candidates per LDS super-panel
+
+__device__ __forceinline__ v4i as_v4i(const uint4& v) { return v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
+
+template <bool PREFILTER>
+__device__ __forceinline__ v16f tile_dot(const v4i (&a)[4], const v4i (&b)[4]) {
+    const v16f z = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    v16f acc = mfma_fp4(a[0], b[0], z);
+    acc = mfma_fp4(a[1], b[1], acc);
+    if (!PREFILTER) {
+        acc = mfma_fp4(a[2], b[2], acc);
+        acc = mfma_fp4(a[3], b[3], acc);
+    }
+    return acc;
+}
+
+// Rare path: some pair of this 32-candidate panel may be within tolerance. Recompute every
+// query tile of the wave over all 256 bits (A fragments are re-read from memory so that the
+// loop stays rolled and the fast path's registers stay untouched) and append the hits.
+template <int TILES>
+__device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, const uint4* base, uint32_t sw,
+                                             uint32_t wrow0, uint32_t j, uint32_t n, uint32_t h, uint32_t li,
+                                             const int32_t* __restrict__ group, float thr_full,
+                                             hvd_pair* __restrict__ out, unsigned long long cap,
+                                             unsigned long long* __restrict__ count) {
+    v4i bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bf[s] = as_v4i(base[(2u * s + h) ^ sw]);
+#pragma unroll 1
+    for (int t = 0; t < TILES; ++t) {
+        const uint32_t hash = wrow0 + 32u * t + li;
+        v4i af[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) af[s] = as_v4i(img[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
+        const v16f acc = tile_dot<false>(af, bf);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            const uint32_t i = wrow0 + 32u * t + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h;
+            if (acc[r] >= thr_full && i < j && j < n) {
+                if (group == nullptr || group[i] != group[j])
+                    append_pair_m(out, cap, count, i, j, (uint32_t)(256 - (int)acc[r]) >> 1);
+            }
+        }
+    }
+}
+
+template <int TILES, bool PREFILTER>
+__global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
+                                                          const int32_t* __restrict__ group, uint32_t max_dist,
+                                                          uint32_t col_chunk, uint32_t rank, uint32_t world,
+                                                          hvd_pair* __restrict__ out, unsigned long long cap,
+                                                          unsigned long long* __restrict__ count) {
+    constexpr uint32_t WROWS = 32u * TILES, ROWS = 4u * WROWS;
+    constexpr int NB = PREFILTER ? 2 : 4;
+    __shared__ uint4 lds[2][kSuper * 8];
+
+    const uint32_t rb = blockIdx.x, cb = blockIdx.y;
+    const uint32_t row0 = rb * ROWS;
+    const uint32_t col0 = cb * col_chunk;
+    const uint32_t col1 = min(col0 + col_chunk, n_pad);
+    if (min(col1, n) <= row0 + 1u) return;  // tile entirely on/below the diagonal
+    if (world > 1u && (rb + cb) % world != rank) return;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, li = lane & 31u, h = lane >> 5;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wrow0 = row0 + wave * WROWS;
+
+    // A fragments: query hash (wrow0 + 32t + li), chunk 2s+h, for the whole tile.
+    v4i a[TILES][4];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const uint32_t hash = wrow0 + 32u * t + li;  // < n_pad by construction
+#pragma unroll
+        for (int s = 0; s < NB; ++s) a[t][s] = as_v4i(img[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
+    }
+
+    const float thr_full = 256.0f - 2.0f * (float)max_dist;                       // > 0 (host guarantees)
+    const float thr_fast = PREFILTER ? 128.0f - 2.0f * (float)max_dist : thr_full;  // may be <= 0: then every
+    const int thr_bits = thr_fast > 0.0f ? __float_as_int(thr_fast) : (int)0x80000000;  // panel takes the slow path
+
+    // candidates <= row0 cannot pair with rows >= row0 (i<j): start at the super-panel holding row0+1
+    const uint32_t j0 = max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
+    const uint32_t nsp = (col1 - j0) / kSuper;  // col0, col1, j0 are multiples of kSuper
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lds[0][tid + 256u * q] = img[(size_t)j0 * 8u + tid + 256u * q];
+    __syncthreads();
+
+    for (uint32_t sp = 0; sp < nsp; ++sp) {
+        const uint32_t buf = sp & 1u;
+        const uint32_t jsp = j0 + sp * kSuper;
+        uint4 pre[4];
+        const bool more = sp + 1u < nsp;
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[q] = img[(size_t)(jsp + kSuper) * 8u + tid + 256u * q];
+        }
+
+#pragma unroll 1
+        for (uint32_t p = 0; p < kSuper / 32; ++p) {
+            const uint32_t cl = 32u * p + li;  // candidate index inside the super-panel
+            const uint4* base = &lds[buf][cl * 8u];
+            const uint32_t sw = (cl >> 1) & 7u;  // jsp is a multiple of 128: same swizzle as the global index
+            v4i b[4];
+#pragma unroll
+            for (int s = 0; s < NB; ++s) b[s] = as_v4i(base[(2u * s + h) ^ sw]);
+
+            // two accumulator sets: the MFMAs of tile t+1 run under the max tree of tile t
+            int mm = (int)0x80000000;
+            v16f cur = tile_dot<PREFILTER>(a[0], b);
+#pragma unroll
+            for (int t = 1; t < TILES; ++t) {
+                const v16f nxt = tile_dot<PREFILTER>(a[t], b);
+                mm = max(mm, max16_bits(cur));
+                cur = nxt;
+            }
+            mm = max(mm, max16_bits(cur));
+
+            if (__builtin_expect(__any(mm >= thr_bits), 0))
+                panel_slow_path<TILES>(img, base, sw, wrow0, jsp + cl, n, h, li, group, thr_full, out, cap, count);
+        }
+
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lds[buf ^ 1u][tid + 256u * q] = pre[q];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+namespace hvd {
+
+static uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+uint32_t fp4_rows_padded(uint32_t n) { return round_up(n ? n : 1, 1024u); }
+
+hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s) {
+    const uint32_t n_pad = fp4_rows_padded(n);
+    const uint64_t threads = (uint64_t)n_pad * 8u;
+    hipLaunchKernelGGL(k_expand_fp4, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_db, n,
+                       n_pad, (uint4*)d_img);
+    return hipGetLastError();
+}
+
+static uint32_t pick_col_chunk_m(uint32_t n_pad, uint32_t rows_per_wg) {
+    uint64_t n_rb = (n_pad + rows_per_wg - 1) / rows_per_wg;
+    uint64_t want_cb = (8192 + n_rb - 1) / n_rb;
+    if (want_cb < 1) want_cb = 1;
+    uint64_t chunk = (n_pad + want_cb - 1) / want_cb;
+    if (chunk < 256) chunk = 256;
+    if (chunk > 4096) chunk = 4096;
+    chunk = (chunk + kSuper - 1) / kSuper * kSuper;
+    if ((n_pad + chunk - 1) / chunk > 65535u) chunk = round_up((n_pad + 65534u) / 65535u, kSuper);
+    return (uint32_t)chunk;
+}
+
+static int mfma_tiles(int variant) {
+    switch (variant) {
+        case 8: case 9: return 8;
+        case 10: case 11: return 4;
+        default: return 0;
+    }
+}
+
+bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk) {
+    const int T = mfma_tiles(variant);
+    if (!T) return false;
+    *rows_per_block = 128u * (uint32_t)T;
+    *col_chunk = pick_col_chunk_m(fp4_rows_padded(n), *rows_per_block);
+    return true;
+}
+
+template <int T, bool PF>
+static hipError_t launch_mfma_t(const AllPairsArgs& a, const void* d_img, hipStream_t s) {
+    const uint32_t n_pad = fp4_rows_padded(a.n);
+    constexpr uint32_t ROWS = 128u * T;
+    const uint32_t chunk = pick_col_chunk_m(n_pad, ROWS);
+    dim3 grid((a.n + ROWS - 1) / ROWS, (n_pad + chunk - 1) / chunk);
+    hipLaunchKernelGGL((k_allpairs_mfma<T, PF>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad, a.d_group,
+                       a.max_dist, chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_allpairs_mfma(const AllPairsArgs& a_in, const void* d_img, hipStream_t s) {
+    if (a_in.n < 2) return hipSuccess;
+    AllPairsArgs a = a_in;
+    // The sign trick of max16_bits needs a positive threshold: 256 - 2*max_dist > 0. Larger
+    // tolerances (never used by the reference, which fixes 31) go to the popcount kernel, which
+    // shares the tile geometry class; the 128-bit prefilter needs 128 - 2*max_dist > 0.
+    if (a.max_dist >= 128u) {
+        if (!a.d_db) return hipErrorInvalidValue;
+        a.variant = 0;
+        return launch_allpairs(a, s);
+    }
+    if (a.max_dist >= 64u && (a.variant == 9 || a.variant == 11)) a.variant -= 1;
+    switch (a.variant) {
+        case 8: return launch_mfma_t<8, false>(a, d_img, s);
+        case 9: return launch_mfma_t<8, true>(a, d_img, s);
+        case 10: return launch_mfma_t<4, false>(a, d_img, s);
+        case 11: return launch_mfma_t<4, true>(a, d_img, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace hvd
