@@ -94,6 +94,9 @@ def main():
     n = int(round(args.hashes * math.sqrt(world) / 1024.0)) * 1024 if world > 1 else args.hashes
     db, planted = synth.hash_db(n, seed=3)
     d_db = L.DeviceBuffer.from_array(db)
+    img_bytes = C.c_size_t(0)
+    L.check(lib.hvd_fp4_image_bytes(n, C.byref(img_bytes)))
+    d_img = L.DeviceBuffer(img_bytes.value)
     cap = 1 << 20
     d_pairs = L.DeviceBuffer(16 * cap)
     d_cnt = L.DeviceBuffer(8)
@@ -103,8 +106,10 @@ def main():
 
     def step(v=variant, timed=True):
         d_cnt.zero()
+        if v >= 8:  # the FP4 image is rebuilt inside every step: it is part of the pass, not a cached index
+            L.check(lib.hvd_dev_expand_fp4(d_db.ptr, n, d_img.ptr))
         L.check(lib.hvd_timer_start())
-        L.check(lib.hvd_dev_allpairs_hamming256(d_db.ptr, n, None, 31, rank, world, d_pairs.ptr, cap, d_cnt.ptr, v))
+        M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n, None, 31, rank, world, d_pairs.ptr, cap, d_cnt.ptr, v)
         ms = C.c_float(0)
         L.check(lib.hvd_timer_stop(C.byref(ms)))  # hipEvents on the library stream; also syncs
         if timed:
@@ -171,23 +176,30 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": f"k_allpairs(variant={variant})", "achieved": round(achieved, 1),
+        "bound": "hbm", "kernel": ("k_allpairs_mfma" if variant >= 8 else "k_allpairs") + f"(variant={variant})",
+        "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 3), "traffic": traffic,
         "kernel_ms": round(kernel_avg_ms, 3),
         "note": "algorithmic bytes = 64 B per comparison with no operand reuse credited (SURVEY.md 8d), so frac > 1 "
-                "means the tiles re-use operands from registers/SGPRs instead of HBM; the binding unit is the "
-                "integer VALU (v_bcnt_u32_b32 issues at half rate, profiles/r01_ubench_valu.txt)",
+                "means the tiles re-use operands from registers/LDS instead of HBM; the binding unit is the matrix "
+                "pipe (v_mfma_f32_32x32x64_f8f6f4 on the +-1 FP4 image) for variants 8..11 and the integer VALU "
+                "(v_bcnt_u32_b32 issues at half rate, profiles/r01_ubench_valu.txt) for variants 0..6",
+        "mfma": (None if variant < 8 else {
+            "instr": "v_mfma_f32_32x32x64_f8f6f4 (fp4 x fp4)", "mfma_per_1024_comparisons": 2 if variant in (9, 11) else 4,
+            "achieved_tflops": round(cmp_per_launch * (256 if variant in (9, 11) else 512) / (kernel_avg_ms * 1e-3) / 1e12, 1),
+            "peak_tflops_dense_fp4": 10000.0}),
     }
 
     extra = {}
     # full-popcount variant next to the default, for transparency (same DB, same launch shape)
     if world == 1:
-        for v, name in ((0, "full_popcount_16op"), (1, "prefilter128_exact")):
+        for v, name in ((0, "popcount_full_16op"), (1, "popcount_prefilter128"), (8, "mfma_fp4_full"),
+                        (9, "mfma_fp4_prefilter128")):
             ks = []
             for r in range(3):
                 d_cnt.zero()
                 L.check(lib.hvd_timer_start())
-                L.check(lib.hvd_dev_allpairs_hamming256(d_db.ptr, n, None, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, v))
+                M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n, None, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, v)
                 ms = C.c_float(0)
                 L.check(lib.hvd_timer_stop(C.byref(ms)))
                 if r:
@@ -254,7 +266,8 @@ def main():
     out = {
         "metric": "hash-pair comparisons/sec", "value": float(f"{value:.5g}"), "unit": "comparisons/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp4(e2m1, +-1 image of the hash bits) x fp4 -> f32, exact" if variant >= 8 else "u32", "data": "synthetic",
         "config": {"workload": f"all-pairs 256-bit Hamming (tolerance 31) over {n} synthetic hashes with planted "
                                f"near-duplicates, {total_cmp:.6g} comparisons per step"
                                + (" (BASELINE configs[2])" if world == 1 and n == 1_000_000 else

@@ -370,12 +370,17 @@ int hvd_pdq_hash_frames_rgb24_u8(const uint8_t* frames, int64_t n, int h, int w,
     return hash_frames_host(frames, n, h, w, 3, out_hashes, out_quality);
 }
 
-// Runs the all-pairs kernel on a host DB; fetches up to `cap` unordered records.
+// Runs the default all-pairs kernel (FP4-MFMA form) on a host DB; fetches up to `cap`
+// unordered records.
 static int allpairs_host_raw(const uint8_t* db, int64_t n, const int32_t* group, int max_dist,
                              std::vector<hvd_pair>& recs, int64_t cap, int64_t* out_count) {
-    DevBuf d_db, d_grp, d_pairs, d_cnt;
+    DevBuf d_db, d_img, d_grp, d_pairs, d_cnt;
     HIP_TRY(d_db.alloc(32 * (size_t)n));
     HIP_TRY(hipMemcpyAsync(d_db.p, db, 32 * (size_t)n, hipMemcpyHostToDevice, g.stream));
+    size_t img_bytes = 0;
+    if (int rc = hvd_fp4_image_bytes(n, &img_bytes)) return rc;
+    HIP_TRY(d_img.alloc(img_bytes));
+    if (int rc = hvd_dev_expand_fp4(d_db.p, n, d_img.p)) return rc;
     if (group) {
         HIP_TRY(d_grp.alloc(4 * (size_t)n));
         HIP_TRY(hipMemcpyAsync(d_grp.p, group, 4 * (size_t)n, hipMemcpyHostToDevice, g.stream));
@@ -383,8 +388,8 @@ static int allpairs_host_raw(const uint8_t* db, int64_t n, const int32_t* group,
     HIP_TRY(d_pairs.alloc(sizeof(hvd_pair) * (size_t)cap));
     HIP_TRY(d_cnt.alloc(8));
     HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 8, g.stream));
-    if (int rc = hvd_dev_allpairs_hamming256(d_db.p, n, group ? d_grp.p : nullptr, max_dist, 0, 1, d_pairs.p, cap,
-                                             d_cnt.p, HVD_DEFAULT_VARIANT))
+    if (int rc = hvd_dev_allpairs_hamming256_mfma(d_db.p, d_img.p, n, group ? d_grp.p : nullptr, max_dist, 0, 1,
+                                                  d_pairs.p, cap, d_cnt.p, HVD_DEFAULT_VARIANT))
         return rc;
     unsigned long long cnt = 0;
     HIP_TRY(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, g.stream));

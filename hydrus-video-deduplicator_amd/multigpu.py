@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import PAIR_DTYPE
 
 
-def tile_geometry(n: int, variant: int = 0) -> tuple[int, int]:
+def tile_geometry(n: int, variant: int = 9) -> tuple[int, int]:
     """(rows_per_block, col_chunk) of the all-pairs launch for n hashes (host-only)."""
     lib = _lib.load()
     r, c = C.c_uint32(0), C.c_uint32(0)
@@ -31,7 +31,7 @@ def tile_owner(rb: int, cb: int, world: int) -> int:
     return (rb + cb) % world
 
 
-def tiles_of_rank(n: int, rank: int, world: int, variant: int = 0):
+def tiles_of_rank(n: int, rank: int, world: int, variant: int = 9):
     """Yield (row0, row1, col0, col1) of the tiles rank owns that intersect the strict
     upper triangle -- the host-side statement of the kernel's tile walk."""
     rows, chunk = tile_geometry(n, variant)
@@ -131,19 +131,47 @@ class TorchDistExchange:
         return np.concatenate(parts) if parts else np.zeros(0, dtype=PAIR_DTYPE)
 
 
+def launch_allpairs(lib, d_db_ptr: int, d_img_ptr: int | None, n: int, d_group_ptr, max_dist: int, rank: int,
+                    world: int, d_pairs_ptr: int, cap: int, d_cnt_ptr: int, variant: int) -> None:
+    """Enqueue one all-pairs pass of this rank's tiles (popcount variants 0..6 on the packed DB,
+    FP4-MFMA variants 8..11 on its FP4 image)."""
+    if variant >= 8:
+        if d_img_ptr is None:
+            raise ValueError("FP4-MFMA variants need the FP4 image (expand_fp4)")
+        _lib.check(lib.hvd_dev_allpairs_hamming256_mfma(d_db_ptr, d_img_ptr, n, d_group_ptr, max_dist, rank, world,
+                                                        d_pairs_ptr, cap, d_cnt_ptr, variant))
+    else:
+        _lib.check(lib.hvd_dev_allpairs_hamming256(d_db_ptr, n, d_group_ptr, max_dist, rank, world, d_pairs_ptr, cap,
+                                                   d_cnt_ptr, variant))
+
+
+def expand_fp4(d_db_ptr: int, n: int) -> "_lib.DeviceBuffer":
+    """FP4 image of a DB resident in HBM (128 bytes per hash, see k_hamming_mfma.hip)."""
+    lib = _lib.ensure()
+    sz = C.c_size_t(0)
+    _lib.check(lib.hvd_fp4_image_bytes(n, C.byref(sz)))
+    d_img = _lib.DeviceBuffer(sz.value)
+    _lib.check(lib.hvd_dev_expand_fp4(d_db_ptr, n, d_img.ptr))
+    return d_img
+
+
 def sharded_allpairs(d_db_ptr: int, n: int, rank: int, world: int, exchange: RcclExchange | None,
-                     max_dist: int = 31, d_group_ptr: int | None = None, variant: int = 0,
+                     max_dist: int = 31, d_group_ptr: int | None = None, variant: int | None = None,
                      cap: int = 1 << 20) -> np.ndarray:
     """Run this rank's tiles on its GPU, exchange, return the full sorted pair list.
     The DB (and group map) must already be resident in this rank's HBM."""
+    from .search import DEFAULT_VARIANT
+
+    variant = DEFAULT_VARIANT if variant is None else variant
     lib = _lib.ensure()
+    d_img = expand_fp4(d_db_ptr, n) if variant >= 8 else None
     d_pairs = _lib.DeviceBuffer(16 * cap)
     d_cnt = _lib.DeviceBuffer(8)
     try:
         while True:
             d_cnt.zero()
-            _lib.check(lib.hvd_dev_allpairs_hamming256(d_db_ptr, n, d_group_ptr, max_dist, rank, world, d_pairs.ptr,
-                                                       cap, d_cnt.ptr, variant))
+            launch_allpairs(lib, d_db_ptr, d_img.ptr if d_img else None, n, d_group_ptr, max_dist, rank, world,
+                            d_pairs.ptr, cap, d_cnt.ptr, variant)
             count = int(d_cnt.to_array(np.uint64, 1)[0])
             if count <= cap:
                 break
@@ -158,3 +186,5 @@ def sharded_allpairs(d_db_ptr: int, n: int, rank: int, world: int, exchange: Rcc
     finally:
         d_pairs.free()
         d_cnt.free()
+        if d_img is not None:
+            d_img.free()

@@ -40,7 +40,7 @@ extern "C" {
 #define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
 #define HVD_UNIQUE_ID_BYTES 128
 #define HVD_ABI_VERSION 1
-#define HVD_DEFAULT_VARIANT 1 /* all-pairs kernel the host entry points use */
+#define HVD_DEFAULT_VARIANT 9 /* all-pairs kernel the host entry points use: FP4-MFMA + 128-bit prefilter */
 
 typedef struct {
     uint32_t i, j, dist, pad;

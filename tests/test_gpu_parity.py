@@ -171,20 +171,58 @@ def test_k2_overflow_is_reported_not_truncated(gpu, hvd):
     assert len(hvd.allpairs_hamming(db, 31, cap=10)) == 300 * 299 // 2  # wrapper retries with the exact size
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+def _run_variant(gpu, hvd, db, variant, max_dist=31, group=None, cap=1 << 16):
+    n = len(db)
+    lib = gpu.load()
+    d_db = gpu.DeviceBuffer.from_array(db)
+    d_img = hvd.multigpu.expand_fp4(d_db.ptr, n) if variant >= 8 else None
+    d_grp = gpu.DeviceBuffer.from_array(group) if group is not None else None
+    d_pairs = gpu.DeviceBuffer(16 * cap)
+    d_cnt = gpu.DeviceBuffer(8)
+    d_cnt.zero()
+    hvd.multigpu.launch_allpairs(lib, d_db.ptr, d_img.ptr if d_img else None, n, d_grp.ptr if d_grp else None,
+                                 max_dist, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, variant)
+    cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+    assert cnt <= cap
+    return hvd.multigpu.merge_pairs([d_pairs.to_array(gpu.PAIR_DTYPE, cnt)])
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11])
 def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
+    """Popcount (0..6) and FP4-MFMA (8..11) forms produce the identical pair list."""
     n = 20000
     db, _ = hvd.synth.hash_db(n, seed=53, plant_fraction=0.01)
     want = oracle.allpairs(db, 31, num_threads=8)
+    assert np.array_equal(_run_variant(gpu, hvd, db, variant), want)
+    grp = (np.arange(n) // 5).astype(np.int32)
+    assert np.array_equal(_run_variant(gpu, hvd, db, variant, group=grp), oracle.allpairs(db, 31, group=grp, num_threads=8))
+
+
+@pytest.mark.parametrize("variant", [8, 9])
+@pytest.mark.parametrize("max_dist", [0, 31, 63, 64, 127, 128, 256])
+def test_k2_mfma_threshold_routing(gpu, hvd, oracle, variant, max_dist):
+    """dot >= 256-2*max_dist is the popcount predicate for every tolerance, including the ones
+    where the prefilter (>= 64) or the sign trick (>= 128) must hand over to another kernel."""
+    db, _ = hvd.synth.hash_db(700, seed=56, plant_fraction=0.05)
+    want = oracle.allpairs(db, max_dist, cap=700 * 700)
+    assert np.array_equal(_run_variant(gpu, hvd, db, variant, max_dist=max_dist, cap=700 * 700), want)
+
+
+def test_fp4_image_layout(gpu, hvd):
+    """Every hash bit b becomes the e2m1 nibble 0x2 (+1.0) or 0xA (-1.0) in chunk (bit/32),
+    stored at slot chunk ^ ((row>>1)&7); padding rows are zero."""
+    n = 300
+    db, _ = hvd.synth.hash_db(n, seed=57, plant_fraction=0.0)
     d_db = gpu.DeviceBuffer.from_array(db)
-    d_pairs = gpu.DeviceBuffer(16 * 4096)
-    d_cnt = gpu.DeviceBuffer(8)
-    d_cnt.zero()
-    gpu.check(gpu.load().hvd_dev_allpairs_hamming256(d_db.ptr, n, None, 31, 0, 1, d_pairs.ptr, 4096, d_cnt.ptr,
-                                                     variant))
-    cnt = int(d_cnt.to_array(np.uint64, 1)[0])
-    got = hvd.multigpu.merge_pairs([d_pairs.to_array(gpu.PAIR_DTYPE, cnt)])
-    assert np.array_equal(got, want)
+    d_img = hvd.multigpu.expand_fp4(d_db.ptr, n)
+    img = d_img.to_array(np.uint8, d_img.nbytes).reshape(-1, 8, 16)
+    assert img.shape[0] == 1024 and not img[n:].any()
+    bits = np.unpackbits(db, axis=1, bitorder="little").reshape(n, 8, 32)
+    for row in (0, 1, 2, 3, 17, 299):
+        for chunk in range(8):
+            raw = img[row, chunk ^ ((row >> 1) & 7)]
+            nib = np.stack([raw & 15, raw >> 4], axis=1).reshape(-1)  # low nibble first
+            assert np.array_equal(nib, np.where(bits[row, chunk] == 1, 0xA, 0x2))
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
@@ -212,7 +250,9 @@ def test_k2_rccl_exchange_single_rank(gpu, hvd):
         d_pairs = gpu.DeviceBuffer(16 * 4096)
         d_cnt = gpu.DeviceBuffer(8)
         d_cnt.zero()
-        gpu.check(gpu.load().hvd_dev_allpairs_hamming256(d_db.ptr, n, None, 31, 0, 1, d_pairs.ptr, 4096, d_cnt.ptr, 0))
+        d_img = hvd.multigpu.expand_fp4(d_db.ptr, n)
+        hvd.multigpu.launch_allpairs(gpu.load(), d_db.ptr, d_img.ptr, n, None, 31, 0, 1, d_pairs.ptr, 4096, d_cnt.ptr,
+                                     hvd.search.DEFAULT_VARIANT)
         cnt = int(d_cnt.to_array(np.uint64, 1)[0])
         got = hvd.multigpu.merge_pairs([ex.allgather_pairs_dev(d_pairs.ptr, cnt)])
         assert np.array_equal(got, hvd.allpairs_hamming(db, 31))
