@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP4_PEAK_TFLOPS = 10000.0     # dense FP4 MFMA peak (MI355X_MICROARCH.md; measured ceiling 9099)
 BYTES_PER_COMPARISON = 64      # two 32-byte operands, no reuse credited
 BYTES_PER_FRAME_64 = 4096 + 32 + 4
 
@@ -175,20 +176,24 @@ def main():
             traffic = tj.get(key)
         except Exception:
             traffic = None
-    roofline = {
-        "bound": "hbm", "kernel": ("k_allpairs_mfma" if variant >= 8 else "k_allpairs") + f"(variant={variant})",
-        "achieved": round(achieved, 1),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 3), "traffic": traffic,
-        "kernel_ms": round(kernel_avg_ms, 3),
-        "note": "algorithmic bytes = 64 B per comparison with no operand reuse credited (SURVEY.md 8d), so frac > 1 "
-                "means the tiles re-use operands from registers/LDS instead of HBM; the binding unit is the matrix "
-                "pipe (v_mfma_f32_32x32x64_f8f6f4 on the +-1 FP4 image) for variants 8..11 and the integer VALU "
-                "(v_bcnt_u32_b32 issues at half rate, profiles/r01_ubench_valu.txt) for variants 0..6",
-        "mfma": (None if variant < 8 else {
-            "instr": "v_mfma_f32_32x32x64_f8f6f4 (fp4 x fp4)", "mfma_per_1024_comparisons": 2 if variant in (9, 11) else 4,
-            "achieved_tflops": round(cmp_per_launch * (256 if variant in (9, 11) else 512) / (kernel_avg_ms * 1e-3) / 1e12, 1),
-            "peak_tflops_dense_fp4": 10000.0}),
-    }
+    hbm_equiv = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(achieved / HBM_PEAK_GBS, 3),
+                 "note": "SURVEY.md 8d accounting: 64 B per comparison with no operand reuse credited; frac > 1 "
+                         "because tiles re-use operands from registers/LDS"}
+    if variant >= 8:
+        # executed matrix work: 2 (prefilter) or 4 MFMAs of 2*32*32*64 flop per 1024 comparisons
+        flop_per_cmp = 256.0 if variant in (9, 11) else 512.0
+        tfl = cmp_per_launch * flop_per_cmp / (kernel_avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": f"k_allpairs_mfma(variant={variant})", "achieved": round(tfl, 1),
+                    "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / FP4_PEAK_TFLOPS, 3),
+                    "traffic": traffic, "kernel_ms": round(kernel_avg_ms, 3),
+                    "instr": "v_mfma_f32_32x32x64_f8f6f4 cbsz:4 blgp:4 on the +-1 FP4 image of the hashes",
+                    "flop_per_comparison_executed": flop_per_cmp, "hbm_equivalent": hbm_equiv}
+    else:
+        roofline = {"bound": "hbm", "kernel": f"k_allpairs(variant={variant})", "traffic": traffic,
+                    "kernel_ms": round(kernel_avg_ms, 3), **hbm_equiv,
+                    "note": hbm_equiv["note"] + "; binding unit: integer VALU (v_bcnt_u32_b32 issues at half rate, "
+                                                "profiles/r01_ubench_valu.txt)"}
 
     extra = {}
     # full-popcount variant next to the default, for transparency (same DB, same launch shape)

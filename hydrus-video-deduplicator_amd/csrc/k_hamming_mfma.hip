@@ -20,7 +20,8 @@
 //
 // Kernel: workgroup = 4 waves; wave w keeps TILES x 32 query hashes as A fragments in
 // VGPRs for the whole tile (TILES*16 VGPRs); candidates stream through LDS in
-// super-panels of 128 hashes (16 KB, double buffered, one barrier per super-panel). For
+// super-panels of 128 hashes (16 KB, double buffered with direct global->LDS loads, one
+// barrier per super-panel). For
 // each 32-candidate panel and each query tile: 2 (PREFILTER: first 128 bits) or 4 MFMAs,
 // a 16-register max tree, and one wave-uniform branch per panel into the rare path that
 // recomputes the full distance and appends the pairs.
@@ -140,6 +141,22 @@ __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, cons
     }
 }
 
+// Stage one 16 KB super-panel (128 hashes x 128 B, contiguous in the image) into LDS with
+// direct global->LDS loads: each wave-instruction moves 64 lanes x 16 B = 1 KB to a
+// wave-uniform LDS base + lane*16, no VGPR round trip (so nothing to keep live -- or spill --
+// across the compute phase). The data is complete after the vmcnt(0) that hipcc places in
+// front of the next __syncthreads().
+__device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src, uint4* lds_dst, uint32_t wave,
+                                                  uint32_t lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t chunk0 = (uint32_t)q * 256u + wave * 64u;  // first 16-B chunk of this wave-instruction
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + chunk0 + lane),
+            (__attribute__((address_space(3))) void*)(lds_dst + chunk0), 16, 0, 0);
+    }
+}
+
 template <int TILES, bool PREFILTER>
 __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
                                                           const int32_t* __restrict__ group, uint32_t max_dist,
@@ -179,19 +196,14 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     const uint32_t j0 = max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
     const uint32_t nsp = (col1 - j0) / kSuper;  // col0, col1, j0 are multiples of kSuper
 
-#pragma unroll
-    for (int q = 0; q < 4; ++q) lds[0][tid + 256u * q] = img[(size_t)j0 * 8u + tid + 256u * q];
+    stage_super_panel(img + (size_t)j0 * 8u, &lds[0][0], wave, lane);
     __syncthreads();
 
     for (uint32_t sp = 0; sp < nsp; ++sp) {
         const uint32_t buf = sp & 1u;
         const uint32_t jsp = j0 + sp * kSuper;
-        uint4 pre[4];
-        const bool more = sp + 1u < nsp;
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pre[q] = img[(size_t)(jsp + kSuper) * 8u + tid + 256u * q];
-        }
+        // buf^1 was last read in iteration sp-1, which every wave left through the barrier below
+        if (sp + 1u < nsp) stage_super_panel(img + (size_t)(jsp + kSuper) * 8u, &lds[buf ^ 1u][0], wave, lane);
 
 #pragma unroll 1
         for (uint32_t p = 0; p < kSuper / 32; ++p) {
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
 #pragma unroll
             for (int t = 1; t < TILES; ++t) {
                 const v16f nxt = tile_dot<PREFILTER>(a[t], b);
-                mm = max(mm, max16_bits(cur));
+                mm = max(mm, max16_bits(cur));  // runs in the shadow of tile t's MFMAs (other accumulator set)
                 cur = nxt;
             }
             mm = max(mm, max16_bits(cur));
@@ -217,11 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
                 panel_slow_path<TILES>(img, base, sw, wrow0, jsp + cl, n, h, li, group, thr_full, out, cap, count);
         }
 
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lds[buf ^ 1u][tid + 256u * q] = pre[q];
-        }
-        __syncthreads();
+        __syncthreads();  // (hipcc drains the in-flight global->LDS loads with vmcnt(0) first)
     }
 }
 
