@@ -213,6 +213,15 @@ int hvd_timer_stop(float* out_ms) {
     return HVD_OK;
 }
 
+int hvd_debug_set(const char* key, int value) {
+    if (!key) return fail(HVD_ERR_ARG, "key is NULL");
+    if (strcmp(key, "pdq_dct_from_lds") == 0) {
+        hvd::g_pdq_dct_from_lds = value != 0;
+        return HVD_OK;
+    }
+    return fail(HVD_ERR_ARG, "unknown debug key %s", key);
+}
+
 int hvd_pdq_scratch_bytes(int64_t n, int h, int w, int channels, size_t* out_bytes) {
     if (!out_bytes || n < 0 || h < 64 || w < 64 || (channels != 1 && channels != 3))
         return fail(HVD_ERR_ARG, "bad frame geometry");

@@ -34,6 +34,7 @@ constexpr int kLd = 68;         // padded LDS row stride (floats): 272 B, 16-B a
 struct alignas(16) PdqLds {
     float T[kWaves][16][kLd];
     float D[16][kLd];
+    float luma_lut[256];  // luma_gray(g) for every byte value
 };
 
 __device__ __forceinline__ float luma_gray(uint32_t g) {
@@ -44,21 +45,33 @@ __device__ __forceinline__ float luma_gray(uint32_t g) {
     return y;
 }
 
-// |(int)(((u - v) * 100) / 255)| as a non-negative integer (pdqhashing.cpp quality metric).
-__device__ __forceinline__ int grad_term(float u, float v) {
-    const float x = __fmul_rn(__fsub_rn(u, v), 100.0f);
-    const int d = (int)__fdiv_rn(x, 255.0f);
-    return d < 0 ? -d : d;
+// |(int)(((u - v) * 100) / 255)| (pdqhashing.cpp quality metric) as a non-negative integer-valued
+// float, WITHOUT the IEEE division (10+ VALU ops): q = |x| * (1/255) is within one of the true
+// quotient's integer part; the remainder r = |x| - 255*trunc(q) is exact in one fma (|x| and
+// 255*m are both multiples of ulp(|x|) and close), and r < 0 / r >= 255 says which way to fix it.
+// Equality with (int)(x / 255.0f) is checked for EVERY float |x| <= 26000 by
+// tests/tools/check_div255.c (2.4e9 values, 0 mismatches); |x| <= 25500.01 here because luma and
+// its box-filter averages never exceed 255.0001. The fma is this kernel's own exact-arithmetic
+// device, not a contraction of reference arithmetic.
+__device__ __forceinline__ float grad_term(float u, float v) {
+    const float ax = fabsf(__fmul_rn(__fsub_rn(u, v), 100.0f));
+    float m = truncf(__fmul_rn(ax, 1.0f / 255.0f));
+    const float r = __fmaf_rn(-255.0f, m, ax);
+    m = r < 0.0f ? m - 1.0f : m;
+    m = r >= 255.0f ? m + 1.0f : m;
+    return m;
 }
 
-__device__ __forceinline__ int wave_sum_i32(int v) {
+__device__ __forceinline__ float wave_sum_f32(float v) {  // exact: integer-valued, far below 2^24
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
 // KIND 0: uint8 gray 64x64 frames. KIND 1: float 64x64 buffers (down-sampler output).
-template <int KIND>
+// DLDS: stage 1 takes D[i][k] from LDS broadcast reads (VGPR operands, full-rate v_mul) instead of
+// scalar loads (SGPR operands: v_mul_f32 s,v issues at half rate, profiles/r01_ubench_valu.txt).
+template <int KIND, bool DLDS>
 __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in, long long n,
                                                     const float* __restrict__ dct, uint8_t* __restrict__ hashes,
                                                     int32_t* __restrict__ quality) {
@@ -68,6 +81,7 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
 
     // Padded LDS copy of the DCT matrix for stage 2 (once per workgroup).
     for (int e = threadIdx.x; e < 16 * 64; e += 256) lds.D[e >> 6][e & 63] = dct[e];
+    lds.luma_lut[threadIdx.x] = luma_gray(threadIdx.x);
     __syncthreads();
 
     const long long groups = (n + kWaves - 1) / kWaves;
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             if (KIND == 0) {
                 const uint8_t* src = reinterpret_cast<const uint8_t*>(in) + f * 4096 + lane;
 #pragma unroll
-                for (int k = 0; k < 64; ++k) a[k] = luma_gray(src[k * 64]);
+                for (int k = 0; k < 64; ++k) a[k] = lds.luma_lut[src[k * 64]];
             } else {
                 const float* src = reinterpret_cast<const float*>(in) + f * 4096 + lane;
 #pragma unroll
@@ -89,16 +103,16 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             }
 
             // ---- quality -----------------------------------------------------------
-            int gsum = 0;
+            float gs = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 63; ++k) gsum += grad_term(a[k], a[k + 1]);
+            for (int k = 0; k < 63; ++k) gs += grad_term(a[k], a[k + 1]);
 #pragma unroll
             for (int k = 0; k < 64; ++k) {
                 const float right = __shfl_down(a[k], 1, 64);
-                const int t = grad_term(a[k], right);
-                gsum += (lane < 63) ? t : 0;
+                const float t = grad_term(a[k], right);
+                gs += (lane < 63) ? t : 0.0f;
             }
-            gsum = wave_sum_i32(gsum);
+            const int gsum = (int)wave_sum_f32(gs);
             int qual = gsum / 90;
             qual = qual > 100 ? 100 : qual;
 
@@ -106,16 +120,35 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
 #pragma unroll 1
             for (int i0 = 0; i0 < 16; i0 += 4) {
                 float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-                const float* d0 = dct + (i0 + 0) * 64;  // wave-uniform -> s_load
-                const float* d1 = dct + (i0 + 1) * 64;
-                const float* d2 = dct + (i0 + 2) * 64;
-                const float* d3 = dct + (i0 + 3) * 64;
+                if (DLDS) {
 #pragma unroll
-                for (int k = 0; k < 64; ++k) {
-                    s0 = __fadd_rn(s0, __fmul_rn(d0[k], a[k]));
-                    s1 = __fadd_rn(s1, __fmul_rn(d1[k], a[k]));
-                    s2 = __fadd_rn(s2, __fmul_rn(d2[k], a[k]));
-                    s3 = __fadd_rn(s3, __fmul_rn(d3[k], a[k]));
+                    for (int k4 = 0; k4 < 16; ++k4) {  // same address in every lane: LDS broadcast
+                        const float4 e0 = *reinterpret_cast<const float4*>(&lds.D[i0 + 0][4 * k4]);
+                        const float4 e1 = *reinterpret_cast<const float4*>(&lds.D[i0 + 1][4 * k4]);
+                        const float4 e2 = *reinterpret_cast<const float4*>(&lds.D[i0 + 2][4 * k4]);
+                        const float4 e3 = *reinterpret_cast<const float4*>(&lds.D[i0 + 3][4 * k4]);
+                        const float x0 = a[4 * k4], x1 = a[4 * k4 + 1], x2 = a[4 * k4 + 2], x3 = a[4 * k4 + 3];
+                        s0 = __fadd_rn(s0, __fmul_rn(e0.x, x0)); s1 = __fadd_rn(s1, __fmul_rn(e1.x, x0));
+                        s2 = __fadd_rn(s2, __fmul_rn(e2.x, x0)); s3 = __fadd_rn(s3, __fmul_rn(e3.x, x0));
+                        s0 = __fadd_rn(s0, __fmul_rn(e0.y, x1)); s1 = __fadd_rn(s1, __fmul_rn(e1.y, x1));
+                        s2 = __fadd_rn(s2, __fmul_rn(e2.y, x1)); s3 = __fadd_rn(s3, __fmul_rn(e3.y, x1));
+                        s0 = __fadd_rn(s0, __fmul_rn(e0.z, x2)); s1 = __fadd_rn(s1, __fmul_rn(e1.z, x2));
+                        s2 = __fadd_rn(s2, __fmul_rn(e2.z, x2)); s3 = __fadd_rn(s3, __fmul_rn(e3.z, x2));
+                        s0 = __fadd_rn(s0, __fmul_rn(e0.w, x3)); s1 = __fadd_rn(s1, __fmul_rn(e1.w, x3));
+                        s2 = __fadd_rn(s2, __fmul_rn(e2.w, x3)); s3 = __fadd_rn(s3, __fmul_rn(e3.w, x3));
+                    }
+                } else {
+                    const float* d0 = dct + (i0 + 0) * 64;  // wave-uniform -> s_load
+                    const float* d1 = dct + (i0 + 1) * 64;
+                    const float* d2 = dct + (i0 + 2) * 64;
+                    const float* d3 = dct + (i0 + 3) * 64;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) {
+                        s0 = __fadd_rn(s0, __fmul_rn(d0[k], a[k]));
+                        s1 = __fadd_rn(s1, __fmul_rn(d1[k], a[k]));
+                        s2 = __fadd_rn(s2, __fmul_rn(d2[k], a[k]));
+                        s3 = __fadd_rn(s3, __fmul_rn(d3[k], a[k]));
+                    }
                 }
                 lds.T[wave][i0 + 0][lane] = s0;
                 lds.T[wave][i0 + 1][lane] = s1;
@@ -292,16 +325,23 @@ __global__ __launch_bounds__(64) void k_box_scan_T(const void* __restrict__ in, 
 
 namespace hvd {
 
+bool g_pdq_dct_from_lds = false;  // A/B switch (hvd_debug_set): stage-1 DCT operand from LDS vs SGPR; measured equal
+
 hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
                              int32_t* d_quality, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int64_t groups = (n + kWaves - 1) / kWaves;
     const int64_t max_grid = 256 * 7;  // 7 workgroups/CU fit by LDS (21.8 KB each)
     dim3 grid((unsigned)(groups < max_grid ? groups : max_grid));
-    if (kind == 0)
-        hipLaunchKernelGGL(k_pdq_hash64<0>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+    const bool dlds = g_pdq_dct_from_lds;
+    if (kind == 0 && dlds)
+        hipLaunchKernelGGL((k_pdq_hash64<0, true>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+    else if (kind == 0)
+        hipLaunchKernelGGL((k_pdq_hash64<0, false>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+    else if (dlds)
+        hipLaunchKernelGGL((k_pdq_hash64<1, true>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
     else
-        hipLaunchKernelGGL(k_pdq_hash64<1>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+        hipLaunchKernelGGL((k_pdq_hash64<1, false>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
     return hipGetLastError();
 }
 

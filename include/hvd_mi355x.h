@@ -112,6 +112,9 @@ int hvd_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int hvd_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 int hvd_dev_sync(void);
 
+/* Developer switches for A/B measurements ("pdq_dct_from_lds": 0|1). Results never change. */
+int hvd_debug_set(const char* key, int value);
+
 /* Bytes of device scratch hvd_dev_pdq_hash_frames needs for this geometry (0 for
  * 64x64 gray): the 64x64 float luma of every frame plus the blur workspace. */
 int hvd_pdq_scratch_bytes(int64_t n, int h, int w, int channels, size_t* out_bytes);

