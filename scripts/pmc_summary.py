@@ -35,8 +35,9 @@ for k in sorted(agg):
     if "TCC_HIT_sum" in c:
         print(f"  -> L2 hit rate    = {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.3f}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["SQ_VALU_MFMA_BUSY_CYCLES"]:
-        # busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is chip cycles of the dispatch
-        print(f"  -> MFMA pipe busy = {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * 1024):.3f} of SIMD-cycles "
-              f"(effective clock {c['GRBM_GUI_ACTIVE'] / (sum(dur[k]) / len(dur[k])) / 1e3:.2f} GHz)")
+        # busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        print(f"  -> MFMA pipe busy = {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):.3f} of SIMD-cycles "
+              f"(dispatch = {cyc:.4g} shader cycles, effective clock {cyc / (sum(dur[k]) / len(dur[k])) / 1e3:.2f} GHz)")
     if "SQ_INSTS_VALU" in c and "SQ_INSTS_MFMA" in c:
         print(f"  -> VALU instr (incl. MFMA) {c['SQ_INSTS_VALU']:.3g}, MFMA {c['SQ_INSTS_MFMA']:.3g}")
