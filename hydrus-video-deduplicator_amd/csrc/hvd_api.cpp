@@ -219,6 +219,10 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_pdq_dct_from_lds = value != 0;
         return HVD_OK;
     }
+    if (strcmp(key, "pdq_fused_down512") == 0) {
+        hvd::g_pdq_fused_down512 = value != 0;
+        return HVD_OK;
+    }
     return fail(HVD_ERR_ARG, "unknown debug key %s", key);
 }
 

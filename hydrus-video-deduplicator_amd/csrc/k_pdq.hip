@@ -321,6 +321,261 @@ __global__ __launch_bounds__(64) void k_box_scan_T(const void* __restrict__ in, 
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Fused down-sampler for the reference's frame geometry, 512x512 (window 4 on both axes):
+// luma + 2 x (rows, cols) Jarosz passes + decimation in ONE kernel, the frame read from HBM
+// exactly once and every intermediate kept in LDS.
+//
+// One workgroup of 512 lanes per frame walks the frame in 17 strips of 32 columns:
+//   A  (all lanes, lane = row)      rep-1 filter along the row, 32 steps, state in registers;
+//                                   outputs land in buf[row][c], c <-> column 32k-2+c (the
+//                                   filter's output lags its input by 2)
+//   B  (wave 0, lane = column)      rep-1 filter down each buffer column, IN PLACE (the lagging
+//                                   operand comes from a 4-register ring, so a row is never read
+//                                   after it was overwritten)
+//   C  (all lanes, lane = row)      rep-2 filter along the row over the buffer columns; emits only
+//                                   the 4 columns per strip that the decimation samples
+//   D  (wave 1, lanes 0..3)         rep-2 filter down each sampled column; emits only the 64
+//                                   sampled rows -> out64[frame][i][j]; runs concurrently with
+//                                   B of the next strip
+// Every filter is upstream's sequential running sum (box1DFloat) with identical operation
+// order, so the result is bit-identical to the 4-launch generic path and to the oracle.
+constexpr int kF = 512;        // frame side
+constexpr int kS = 32;         // strip width
+constexpr int kBufLd = kS + 1; // odd row stride: lane=row accesses are bank-conflict free
+constexpr int kCsLd = kF + 1;
+
+template <int CH>
+struct StripRaw {
+    uint4 q[CH == 3 ? 6 : 2];
+};
+
+template <int CH>
+__device__ __forceinline__ void load_strip_raw(const uint8_t* __restrict__ row_ptr, int k, StripRaw<CH>& raw) {
+    const uint4* p = reinterpret_cast<const uint4*>(row_ptr + (CH == 3 ? 96 : 32) * k);  // 32 px, 16-B aligned
+#pragma unroll
+    for (int q = 0; q < (CH == 3 ? 6 : 2); ++q) raw.q[q] = p[q];
+}
+
+template <int CH>
+__device__ __forceinline__ void strip_luma(const StripRaw<CH>& raw, float (&v)[kS]) {
+    if (CH == 3) {
+        uint32_t w[24];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const uint4 t = raw.q[q];
+            w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int c = 0; c < kS; ++c) {
+            const int b0 = 3 * c, b1 = 3 * c + 1, b2 = 3 * c + 2;
+            const float r = (float)((w[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu);
+            const float g = (float)((w[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu);
+            const float b = (float)((w[b2 >> 2] >> (8 * (b2 & 3))) & 0xFFu);
+            float yv = __fmul_rn(0.299f, r);
+            yv = __fadd_rn(yv, __fmul_rn(0.587f, g));
+            yv = __fadd_rn(yv, __fmul_rn(0.114f, b));
+            v[c] = yv;
+        }
+    } else {
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint4 t = raw.q[q];
+            w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int c = 0; c < kS; ++c) v[c] = luma_gray((w[c >> 2] >> (8 * (c & 3))) & 0xFFu);
+    }
+}
+
+// One 1-D Jarosz pass (window 4, 512 elements) down an LDS column, as a single lane's
+// sequential recurrence. INPLACE (pass B): every output is written back to the column, two
+// rows behind the read position (the lagging operand lives in registers, so a row is never
+// read after it was overwritten). Otherwise (pass D): only the decimation samples
+// oy = 8i+4 (produced at step s = 8i+6, full window) go to dst[i*64 + j].
+// The main loop handles 8 steps per trip with the next 8 values already in flight; the code is
+// branch-free inside a trip because a lone wave is issue-bound here.
+#define HVD_COL_STEP(X, L)            \
+    sum = __fadd_rn(sum, (X));        \
+    sum = __fsub_rn(sum, (L));        \
+    (L) = (X);
+
+template <bool INPLACE>
+__device__ __forceinline__ void column_pass512(float* col, const int stride, float* __restrict__ dst, const int j) {
+    float x0 = col[0], x1 = col[stride], x2 = col[2 * stride], x3 = col[3 * stride];
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = col[(4 + e) * stride];
+    float sum = __fadd_rn(__fadd_rn(x0, x1), x2);  // ((0 + x0) + x1) + x2; 0 + x0 is exact
+    if (INPLACE) col[0] = __fdiv_rn(sum, 3.0f);
+    sum = __fadd_rn(sum, x3);
+    if (INPLACE) col[stride] = __fmul_rn(sum, 0.25f);
+    float l0 = x0, l1 = x1, l2 = x2, l3 = x3;
+
+    // steps s0 .. s0+7 with the values in v[]; outputs are rows s0-2 .. s0+5
+#define HVD_COL_CHUNK(V, S0)                                                                   \
+    {                                                                                          \
+        float o[8];                                                                            \
+        HVD_COL_STEP(V[0], l0) o[0] = sum; HVD_COL_STEP(V[1], l1) o[1] = sum;                  \
+        HVD_COL_STEP(V[2], l2) o[2] = sum; HVD_COL_STEP(V[3], l3) o[3] = sum;                  \
+        HVD_COL_STEP(V[4], l0) o[4] = sum; HVD_COL_STEP(V[5], l1) o[5] = sum;                  \
+        HVD_COL_STEP(V[6], l2) o[6] = sum; HVD_COL_STEP(V[7], l3) o[7] = sum;                  \
+        if (INPLACE) {                                                                         \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e)                                      \
+                col[((S0) - 2 + e) * stride] = __fmul_rn(o[e], 0.25f);                         \
+        } else {                                                                               \
+            dst[(((S0) - 4) >> 3) * 64 + j] = __fmul_rn(o[2], 0.25f); /* step S0+2 = 8i+6 */   \
+        }                                                                                      \
+    }
+
+    // main: s0 = 4, 12, ..., 492 (62 trips of 8 steps, unrolled in pairs so that a/b swap statically)
+#pragma unroll 1
+    for (int s0 = 4; s0 < 500; s0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = col[(s0 + 8 + e) * stride];
+        HVD_COL_CHUNK(a, s0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = col[(s0 + 16 + e) * stride];
+        HVD_COL_CHUNK(b, s0 + 8)
+    }
+    // here a[] holds rows 500..507; rows 508..511 remain
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = col[(508 + e) * stride];
+    HVD_COL_CHUNK(a, 500)
+    {
+        float o[4];
+        HVD_COL_STEP(t[0], l0) o[0] = sum; HVD_COL_STEP(t[1], l1) o[1] = sum;
+        HVD_COL_STEP(t[2], l2) o[2] = sum; HVD_COL_STEP(t[3], l3) o[3] = sum;
+        if (INPLACE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) col[(506 + e) * stride] = __fmul_rn(o[e], 0.25f);
+        } else {
+            dst[63 * 64 + j] = __fmul_rn(o[2], 0.25f);  // step 510 = 8*63 + 6
+        }
+    }
+    if (INPLACE) {  // box1DFloat phase 4: outputs 510 (/3) and 511 (/2)
+        sum = __fsub_rn(sum, l0);
+        col[510 * stride] = __fdiv_rn(sum, 3.0f);
+        sum = __fsub_rn(sum, l1);
+        col[511 * stride] = __fmul_rn(sum, 0.5f);
+    }
+#undef HVD_COL_CHUNK
+}
+#undef HVD_COL_STEP
+
+template <int CH>
+__global__ __launch_bounds__(512, 4) void k_down512(  // 4 waves/SIMD = 2 workgroups/CU: <= 128 VGPRs
+    const uint8_t* __restrict__ frames, long long n,
+                                                 float* __restrict__ out64) {
+    __shared__ float buf[kF][kBufLd];
+    __shared__ float cs[4][kCsLd];
+    const int y = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    for (long long f = blockIdx.x; f < n; f += gridDim.x) {
+        const uint8_t* row_ptr = frames + (size_t)f * kF * kF * CH + (size_t)y * kF * CH;
+        float* dst = out64 + (size_t)f * 4096;
+        float sA = 0.0f, lagA[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float sC = 0.0f, lagC[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        StripRaw<CH> raw;
+        load_strip_raw<CH>(row_ptr, 0, raw);
+
+#pragma unroll 1
+        for (int k = 0; k <= 16; ++k) {
+            // ---------------- A: rep-1 along the row -------------------------------------
+            if (k < 16) {
+                float v[kS];
+                strip_luma<CH>(raw, v);
+                if (k < 15) load_strip_raw<CH>(row_ptr, k + 1, raw);  // in flight during B/C of this strip
+                if (k == 0) {
+                    // s = 0,1: accumulate only; s = 2: /3; s = 3: /4 (box1DFloat phases 1-2)
+                    sA = __fadd_rn(sA, v[0]);
+                    sA = __fadd_rn(sA, v[1]);
+                    sA = __fadd_rn(sA, v[2]);
+                    buf[y][2] = __fdiv_rn(sA, 3.0f);
+                    sA = __fadd_rn(sA, v[3]);
+                    buf[y][3] = __fmul_rn(sA, 0.25f);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lagA[c] = v[c];
+#pragma unroll
+                    for (int c = 4; c < kS; ++c) {
+                        sA = __fadd_rn(sA, v[c]);
+                        sA = __fsub_rn(sA, lagA[c & 3]);
+                        lagA[c & 3] = v[c];
+                        buf[y][c] = __fmul_rn(sA, 0.25f);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < kS; ++c) {
+                        sA = __fadd_rn(sA, v[c]);
+                        sA = __fsub_rn(sA, lagA[c & 3]);
+                        lagA[c & 3] = v[c];
+                        buf[y][c] = __fmul_rn(sA, 0.25f);
+                    }
+                }
+            } else {
+                // s = 512, 513 (phase 4): outputs 510 (/3) and 511 (/2)
+                sA = __fsub_rn(sA, lagA[0]);
+                buf[y][0] = __fdiv_rn(sA, 3.0f);
+                sA = __fsub_rn(sA, lagA[1]);
+                buf[y][1] = __fmul_rn(sA, 0.5f);
+            }
+            __syncthreads();
+
+            // ---------------- B: rep-1 down the buffer columns (in place) ‖ D of strip k-1 ----
+            const int c_lo = (k == 0) ? 2 : 0, c_hi = (k == 16) ? 2 : kS;
+            if (wave == 0) {
+                const int c = lane;
+                if (c >= c_lo && c < c_hi) column_pass512<true>(&buf[0][c], kBufLd, nullptr, 0);
+            } else if (wave == 1 && k > 0) {
+                // D: samples written by C of strip k-1: slot jj <-> sample column j = 4(k-1) - 1 + jj
+                const int jj = lane, j = 4 * (k - 1) - 1 + jj;
+                if (jj < 4 && j >= 0 && j < 64) column_pass512<false>(cs[jj], 1, dst, j);
+            }
+            __syncthreads();
+
+            // ---------------- C: rep-2 along the row over the buffer columns ------------------
+            // buffer column c <-> filter input index t = 32k - 2 + c; ring slot t & 3 = (c + 2) & 3;
+            // the output t - 2 is a decimation sample iff c is a multiple of 8 (slot c / 8)
+            if (k == 0) {
+                // t = 0..29 <-> c = 2..31
+                const float t0 = buf[y][2], t1 = buf[y][3], t2 = buf[y][4], t3 = buf[y][5];
+                sC = __fadd_rn(__fadd_rn(__fadd_rn(t0, t1), t2), t3);
+                lagC[0] = t0; lagC[1] = t1; lagC[2] = t2; lagC[3] = t3;
+#pragma unroll
+                for (int c = 6; c < kS; ++c) {
+                    const float x = buf[y][c];
+                    sC = __fsub_rn(__fadd_rn(sC, x), lagC[(c + 2) & 3]);
+                    lagC[(c + 2) & 3] = x;
+                    if ((c & 7) == 0) cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
+                }
+            } else if (k < 16) {
+#pragma unroll
+                for (int c = 0; c < kS; ++c) {
+                    const float x = buf[y][c];
+                    sC = __fsub_rn(__fadd_rn(sC, x), lagC[(c + 2) & 3]);
+                    lagC[(c + 2) & 3] = x;
+                    if ((c & 7) == 0) cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
+                }
+            } else {
+                // t = 510: output 508 = sample column 63 (slot 0); t = 511 feeds nothing that is sampled
+                const float x = buf[y][0];
+                sC = __fsub_rn(__fadd_rn(sC, x), lagC[2]);
+                cs[0][y] = __fmul_rn(sC, 0.25f);
+            }
+            __syncthreads();
+        }
+
+        // D for the last strip's single sample column (j = 63)
+        if (wave == 1 && lane == 0) column_pass512<false>(cs[0], 1, dst, 63);
+        __syncthreads();  // cs / buf are reused by the next frame
+    }
+}
+
 }  // namespace
 
 namespace hvd {
@@ -350,9 +605,19 @@ static int jarosz_window(int dim) { return (dim + 2 * 64 - 1) / (2 * 64); }
 // Workspace (floats per frame) the down-sampler needs besides the 64x64 output.
 size_t pdq_downsample_ws_floats(int h, int w) { return 2 * (size_t)h * w + (size_t)64 * h; }
 
+bool g_pdq_fused_down512 = true;  // A/B switch (hvd_debug_set "pdq_fused_down512")
+
 hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int w, int channels, float* d_ws,
                                  float* d_out64, hipStream_t s) {
     if (n <= 0) return hipSuccess;
+    if (h == kF && w == kF && g_pdq_fused_down512) {
+        const unsigned grid = (unsigned)(n < 512 ? n : 512);  // 2 workgroups per CU fit by LDS (75.8 KB each)
+        if (channels == 3)
+            hipLaunchKernelGGL(k_down512<3>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+        else
+            hipLaunchKernelGGL(k_down512<1>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+        return hipGetLastError();
+    }
     if (jarosz_window(h) > kTW || jarosz_window(w) > kTW) return hipErrorInvalidValue;
     const size_t hw = (size_t)h * w;
     const int win_rows = jarosz_window(w);  // window of the filter that runs along a row
