@@ -51,6 +51,12 @@ struct Ctx {
     bool comm_ready = false;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    // grow-only staging for the candidate-pair exchange (no malloc/free inside a step)
+    void* x_cnt_in = nullptr;
+    void* x_cnt_all = nullptr;
+    void* x_send = nullptr;
+    void* x_recv = nullptr;
+    size_t x_send_cap = 0, x_recv_cap = 0;
 };
 Ctx g;
 std::mutex g_mu;
@@ -83,6 +89,8 @@ int need_ready() {
 bool pair_less(const hvd_pair& x, const hvd_pair& y) { return x.i != y.i ? x.i < y.i : x.j < y.j; }
 
 }  // namespace
+
+static void free_exchange_buffers();
 
 extern "C" {
 
@@ -144,11 +152,12 @@ int hvd_init(int device) {
 int hvd_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.ready) return HVD_OK;
+    (void)hipStreamSynchronize(g.stream);
     if (g.comm_ready) {
+        free_exchange_buffers();
         (void)ncclCommDestroy(g.comm);
         g.comm_ready = false;
     }
-    (void)hipStreamSynchronize(g.stream);
     (void)hipFree(g.d_dct);
     (void)hipEventDestroy(g.ev0);
     (void)hipEventDestroy(g.ev1);
@@ -555,8 +564,19 @@ int hvd_comm_init(const uint8_t id_bytes[HVD_UNIQUE_ID_BYTES], int rank, int wor
     return HVD_OK;
 }
 
+static void free_exchange_buffers() {
+    void** ps[] = {&g.x_cnt_in, &g.x_cnt_all, &g.x_send, &g.x_recv};
+    for (void** p : ps) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    g.x_send_cap = g.x_recv_cap = 0;
+}
+
 int hvd_comm_destroy(void) {
     if (g.comm_ready) {
+        (void)hipStreamSynchronize(g.stream);
+        free_exchange_buffers();
         NCCL_TRY(ncclCommDestroy(g.comm));
         g.comm_ready = false;
     }
@@ -570,6 +590,17 @@ int hvd_comm_allgather_bytes(const void* d_send, void* d_recv, size_t bytes_per_
     return HVD_OK;
 }
 
+static int grow(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return HVD_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need < (1u << 16) ? (1u << 16) : need + need / 2;
+    HIP_TRY(hipMalloc(p, want));
+    *cap = want;
+    return HVD_OK;
+}
+
 int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_host, int64_t cap,
                              int64_t* out_total) {
     if (int rc = need_ready()) return rc;
@@ -577,14 +608,13 @@ int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_h
     if (count < 0 || cap < 0 || !out_total) return fail(HVD_ERR_ARG, "bad arguments");
     const int W = g.world;
     // 1) counts
-    DevBuf d_cnt_in, d_cnt_all;
-    HIP_TRY(d_cnt_in.alloc(8));
-    HIP_TRY(d_cnt_all.alloc(8 * (size_t)W));
+    if (!g.x_cnt_in) HIP_TRY(hipMalloc(&g.x_cnt_in, 8));
+    if (!g.x_cnt_all) HIP_TRY(hipMalloc(&g.x_cnt_all, 8 * (size_t)W));
     unsigned long long c = (unsigned long long)count;
-    HIP_TRY(hipMemcpyAsync(d_cnt_in.p, &c, 8, hipMemcpyHostToDevice, g.stream));
-    NCCL_TRY(ncclAllGather(d_cnt_in.p, d_cnt_all.p, 1, ncclUint64, g.comm, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.x_cnt_in, &c, 8, hipMemcpyHostToDevice, g.stream));
+    NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 1, ncclUint64, g.comm, g.stream));
     std::vector<unsigned long long> counts((size_t)W);
-    HIP_TRY(hipMemcpyAsync(counts.data(), d_cnt_all.p, 8 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(counts.data(), g.x_cnt_all, 8 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     unsigned long long mx = 0, total = 0;
     for (int r = 0; r < W; ++r) {
@@ -596,15 +626,16 @@ int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_h
     if (total == 0) return HVD_OK;
     if (!out_host) return fail(HVD_ERR_ARG, "out_host is NULL");
     // 2) records, padded to the max count so that one all-gather suffices
-    DevBuf d_send, d_recv;
-    HIP_TRY(d_send.alloc(sizeof(hvd_pair) * (size_t)mx));
-    HIP_TRY(d_recv.alloc(sizeof(hvd_pair) * (size_t)mx * (size_t)W));
-    HIP_TRY(hipMemsetAsync(d_send.p, 0, sizeof(hvd_pair) * (size_t)mx, g.stream));
+    if (int rc = grow(&g.x_send, &g.x_send_cap, sizeof(hvd_pair) * (size_t)mx)) return rc;
+    if (int rc = grow(&g.x_recv, &g.x_recv_cap, sizeof(hvd_pair) * (size_t)mx * (size_t)W)) return rc;
+    if ((unsigned long long)count < mx)
+        HIP_TRY(hipMemsetAsync((char*)g.x_send + sizeof(hvd_pair) * (size_t)count, 0,
+                               sizeof(hvd_pair) * (size_t)(mx - (unsigned long long)count), g.stream));
     if (count > 0)
-        HIP_TRY(hipMemcpyAsync(d_send.p, d_pairs, sizeof(hvd_pair) * (size_t)count, hipMemcpyDeviceToDevice, g.stream));
-    NCCL_TRY(ncclAllGather(d_send.p, d_recv.p, sizeof(hvd_pair) * (size_t)mx, ncclUint8, g.comm, g.stream));
+        HIP_TRY(hipMemcpyAsync(g.x_send, d_pairs, sizeof(hvd_pair) * (size_t)count, hipMemcpyDeviceToDevice, g.stream));
+    NCCL_TRY(ncclAllGather(g.x_send, g.x_recv, sizeof(hvd_pair) * (size_t)mx, ncclUint8, g.comm, g.stream));
     std::vector<hvd_pair> all((size_t)mx * (size_t)W);
-    HIP_TRY(hipMemcpyAsync(all.data(), d_recv.p, sizeof(hvd_pair) * all.size(), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(all.data(), g.x_recv, sizeof(hvd_pair) * all.size(), hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     size_t o = 0;
     for (int r = 0; r < W; ++r) {

@@ -373,3 +373,47 @@ def test_end_to_end_hash_then_search(gpu, hvd, oracle):
     assert dup == want
     planted = {(min(s_, d_), max(s_, d_)) for d_, s_ in copies.items()}
     assert len(planted & set(dup)) >= 2  # noisy copies of high-contrast videos stay within tolerance
+
+
+def test_pipeline_hash_videos_matches_per_video_path(gpu, hvd, oracle):
+    rng = np.random.default_rng(66)
+    lens = [0, 1, 7, 16, 3]
+    frames = hvd.synth.frames_gray(sum(lens), seed=67)
+    vids, pos = [], 0
+    for n in lens:
+        vids.append(frames[pos:pos + n])
+        pos += n
+    ph = hvd.hash_videos(vids)
+    for v, p in zip(vids, ph):
+        assert p == (hvd.compute_phash(v) if len(v) else hvd.VpdqHash(b""))
+    _, pairs = hvd.dedupe_videos(vids + [vids[3].copy()], threshold=50.0)
+    if len(ph[3]):
+        assert (3, 5) in pairs
+
+
+def test_k3_full_size_config5_properties(gpu, hvd):
+    """BASELINE config 5 search half at full size: 50k videos x 64 frame hashes = 3.2M frames,
+    ~5.1e12 frame comparisons, 1.25e9 video pairs. Size-independent properties: every planted
+    near-copy is reported with full counters, every record verifies against the per-pair entry
+    point on a sample, nothing is reported between unrelated (uniform random) videos."""
+    V, F = 50_000, 64
+    frames, offsets, planted = hvd.synth.video_hashes(V, seed=5, frames_per_video=F, copy_fraction=0.02, max_flips=24)
+    recs = hvd.match_videos(frames, offsets, 31)
+    got = {(int(r["a"]), int(r["b"])): (int(r["q_hits"]), int(r["t_hits"])) for r in recs}
+    assert len(planted) >= 900
+    full = 0
+    for idx, (s_, d_) in enumerate(planted):
+        q, t = got[(int(s_), int(d_))]  # KeyError = a planted copy was missed
+        if idx % 2 == 0:
+            assert (q, t) == (F, F)
+            full += 1
+        else:
+            assert q >= F // 2 and t >= F // 2
+    assert full > 400
+    # chains (copy of a copy) add a few records; unrelated videos add none
+    assert len(planted) <= len(got) <= len(planted) + len(planted) // 5
+    for (a, b), (q, t) in list(got.items())[:20]:
+        assert hvd.vpdq.match_counts(frames[offsets[a]:offsets[a + 1]].tobytes(),
+                                     frames[offsets[b]:offsets[b + 1]].tobytes(), 31) == (q, t)
+    pairs = hvd.search.similar_video_pairs(recs, np.diff(offsets), 50.0)
+    assert len(pairs) >= len(planted) * 0.95
