@@ -40,6 +40,8 @@ SIGNATURES = {
     "hvd_allpairs_hamming256": (_int, [_vp, _i64, _vp, _int, _vp, _i64, C.POINTER(_i64)]),
     "hvd_match_two": (_int, [_vp, _i64, _vp, _i64, _int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hvd_vpdq_match_videos": (_int, [_vp, _vp, _i64, _int, _vp, _i64, C.POINTER(_i64)]),
+    "hvd_vpdq_match_videos_cross": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _int, _vp, _i64,
+                                           C.POINTER(_i64)]),
     "hvd_dev_malloc": (_int, [C.POINTER(_vp), _sz]),
     "hvd_dev_free": (_int, [_vp]),
     "hvd_dev_memset": (_int, [_vp, _int, _sz]),
@@ -53,6 +55,7 @@ SIGNATURES = {
     "hvd_fp4_image_bytes": (_int, [_i64, C.POINTER(_sz)]),
     "hvd_dev_expand_fp4": (_int, [_vp, _i64, _vp]),
     "hvd_dev_allpairs_hamming256_mfma": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _i64, _vp, _int]),
+    "hvd_dev_cross_hamming256_mfma": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _int, _int, _int, _vp, _i64, _vp]),
     "hvd_allpairs_tile_geometry": (_int, [_i64, _int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "hvd_timer_start": (_int, []),
     "hvd_timer_stop": (_int, [C.POINTER(C.c_float)]),

@@ -347,6 +347,35 @@ int hvd_dev_allpairs_hamming256(const void* d_db, int64_t n, const void* d_group
     return HVD_OK;
 }
 
+int hvd_dev_cross_hamming256_mfma(const void* d_img_q, int64_t nq, const void* d_img_t, int64_t nt,
+                                  const void* d_group_q, const void* d_group_t, int max_dist, int rank, int world,
+                                  void* d_pairs, int64_t cap, void* d_count) {
+    if (int rc = need_ready()) return rc;
+    if (nq < 0 || nt < 0 || nq >= (1ll << 32) || nt >= (1ll << 32)) return fail(HVD_ERR_ARG, "set size out of range");
+    if (max_dist < 0 || max_dist >= 128)
+        return fail(HVD_ERR_ARG, "cross search supports max_dist in [0,127] (the reference uses 31), got %d", max_dist);
+    if (world < 1 || rank < 0 || rank >= world) return fail(HVD_ERR_ARG, "bad rank/world %d/%d", rank, world);
+    if (cap < 0 || !d_count || (cap > 0 && !d_pairs)) return fail(HVD_ERR_ARG, "bad output buffer");
+    if ((d_group_q == nullptr) != (d_group_t == nullptr)) return fail(HVD_ERR_ARG, "pass both group maps or neither");
+    if (nq == 0 || nt == 0) return HVD_OK;
+    if (!d_img_q || !d_img_t) return fail(HVD_ERR_ARG, "NULL image");
+    hvd::AllPairsArgs a;
+    a.d_db = nullptr;
+    a.n = (uint32_t)nt;
+    a.d_group = (const int32_t*)d_group_q;
+    a.max_dist = (uint32_t)max_dist;
+    a.rank = (uint32_t)rank;
+    a.world = (uint32_t)world;
+    a.d_pairs = (hvd_pair*)d_pairs;
+    a.cap = (unsigned long long)cap;
+    a.d_count = (unsigned long long*)d_count;
+    a.variant = HVD_DEFAULT_VARIANT;
+    a.col_chunk = 0;
+    hipError_t e = hvd::launch_cross_mfma(a, d_img_q, (uint32_t)nq, d_img_t, (const int32_t*)d_group_t, g.stream);
+    if (e != hipSuccess) return fail(HVD_ERR_HIP, "launch_cross_mfma: %s", hipGetErrorString(e));
+    return HVD_OK;
+}
+
 /* ------------------------------------------------- host-buffer entry points -- */
 
 static int hash_frames_host(const uint8_t* frames, int64_t n, int h, int w, int channels, uint8_t* out_hashes,
@@ -445,6 +474,45 @@ int hvd_allpairs_hamming256(const uint8_t* db, int64_t n, const int32_t* group, 
     return HVD_OK;
 }
 
+// Frame-level hits -> per video pair (a = video of the row frame, b = video of the column frame):
+// q_hits = distinct row frames, t_hits = distinct column frames. Output sorted by (a, b).
+static void aggregate_video_hits(const std::vector<hvd_pair>& recs, const int32_t* vid_row, const int32_t* vid_col,
+                                 std::vector<hvd_vmatch>& res) {
+    struct Key {
+        uint32_t a, b, f;
+    };
+    std::vector<Key> qs(recs.size()), ts(recs.size());
+    for (size_t k = 0; k < recs.size(); ++k) {
+        const uint32_t va = (uint32_t)vid_row[recs[k].i], vb = (uint32_t)vid_col[recs[k].j];
+        qs[k] = Key{va, vb, recs[k].i};
+        ts[k] = Key{va, vb, recs[k].j};
+    }
+    auto less = [](const Key& x, const Key& y) {
+        if (x.a != y.a) return x.a < y.a;
+        if (x.b != y.b) return x.b < y.b;
+        return x.f < y.f;
+    };
+    std::sort(qs.begin(), qs.end(), less);
+    std::sort(ts.begin(), ts.end(), less);
+    res.clear();
+    size_t qi = 0, ti = 0;
+    while (qi < qs.size()) {
+        const uint32_t a = qs[qi].a, b = qs[qi].b;
+        uint32_t qh = 0, th = 0;
+        for (uint32_t last = 0xFFFFFFFFu; qi < qs.size() && qs[qi].a == a && qs[qi].b == b; ++qi)
+            if (qs[qi].f != last) {
+                last = qs[qi].f;
+                ++qh;
+            }
+        for (uint32_t last = 0xFFFFFFFFu; ti < ts.size() && ts[ti].a == a && ts[ti].b == b; ++ti)
+            if (ts[ti].f != last) {
+                last = ts[ti].f;
+                ++th;
+            }
+        res.push_back(hvd_vmatch{a, b, qh, th});
+    }
+}
+
 int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, int max_dist, int32_t* q_hits,
                   int32_t* t_hits) {
     if (int rc = need_ready()) return rc;
@@ -497,40 +565,98 @@ int hvd_vpdq_match_videos(const uint8_t* frames, const int64_t* offsets, int64_t
         if (fcount <= fcap) break;
         fcap = fcount;
     }
-    // Aggregate: per video pair, distinct query frames and distinct target frames.
-    struct Key {
-        uint32_t a, b, f;
-    };
-    std::vector<Key> qs(recs.size()), ts(recs.size());
-    for (size_t k = 0; k < recs.size(); ++k) {
-        const uint32_t va = (uint32_t)vid[recs[k].i], vb = (uint32_t)vid[recs[k].j];  // i<j and CSR order => va<vb
-        qs[k] = Key{va, vb, recs[k].i};
-        ts[k] = Key{va, vb, recs[k].j};
-    }
-    auto less = [](const Key& x, const Key& y) {
-        if (x.a != y.a) return x.a < y.a;
-        if (x.b != y.b) return x.b < y.b;
-        return x.f < y.f;
-    };
-    std::sort(qs.begin(), qs.end(), less);
-    std::sort(ts.begin(), ts.end(), less);
     std::vector<hvd_vmatch> res;
-    size_t qi = 0, ti = 0;
-    while (qi < qs.size()) {
-        const uint32_t a = qs[qi].a, b = qs[qi].b;
-        uint32_t qh = 0, th = 0;
-        for (uint32_t last = 0xFFFFFFFFu; qi < qs.size() && qs[qi].a == a && qs[qi].b == b; ++qi)
-            if (qs[qi].f != last) {
-                last = qs[qi].f;
-                ++qh;
-            }
-        for (uint32_t last = 0xFFFFFFFFu; ti < ts.size() && ts[ti].a == a && ts[ti].b == b; ++ti)
-            if (ts[ti].f != last) {
-                last = ts[ti].f;
-                ++th;
-            }
-        res.push_back(hvd_vmatch{a, b, qh, th});
+    aggregate_video_hits(recs, vid.data(), vid.data(), res);
+    *out_count = (int64_t)res.size();
+    if ((int64_t)res.size() > cap)
+        return fail(HVD_ERR_OVERFLOW, "video match buffer too small: need %lld, cap %lld", (long long)res.size(),
+                    (long long)cap);
+    if (!res.empty()) memcpy(out, res.data(), sizeof(hvd_vmatch) * res.size());
+    return HVD_OK;
+}
+
+static int check_offsets(const int64_t* offsets, int64_t V, int64_t* nf) {
+    if (V < 0 || !offsets) return fail(HVD_ERR_ARG, "bad offsets");
+    if (offsets[0] != 0) return fail(HVD_ERR_ARG, "offsets[0] must be 0");
+    for (int64_t v = 0; v < V; ++v)
+        if (offsets[v + 1] < offsets[v]) return fail(HVD_ERR_ARG, "offsets must be non-decreasing");
+    *nf = V > 0 ? offsets[V] : 0;
+    if (*nf >= (1ll << 32) || V >= (1ll << 31)) return fail(HVD_ERR_ARG, "too many frames/videos");
+    return HVD_OK;
+}
+
+int hvd_vpdq_match_videos_cross(const uint8_t* frames_q, const int64_t* offsets_q, int64_t VQ, const int32_t* ids_q,
+                                const uint8_t* frames_t, const int64_t* offsets_t, int64_t VT, const int32_t* ids_t,
+                                int max_dist, hvd_vmatch* out, int64_t cap, int64_t* out_count) {
+    if (int rc = need_ready()) return rc;
+    if (!out_count || cap < 0 || (cap > 0 && !out)) return fail(HVD_ERR_ARG, "bad output buffer");
+    if ((ids_q == nullptr) != (ids_t == nullptr)) return fail(HVD_ERR_ARG, "pass both id arrays or neither");
+    if (max_dist < 0 || max_dist >= 128) return fail(HVD_ERR_ARG, "max_dist=%d out of range [0,127]", max_dist);
+    *out_count = 0;
+    int64_t nq = 0, nt = 0;
+    if (int rc = check_offsets(offsets_q, VQ, &nq)) return rc;
+    if (int rc = check_offsets(offsets_t, VT, &nt)) return rc;
+    if (nq == 0 || nt == 0) return HVD_OK;
+    if (!frames_q || !frames_t) return fail(HVD_ERR_ARG, "frames is NULL");
+    std::vector<int32_t> vq((size_t)nq), vt((size_t)nt), gq, gt;
+    for (int64_t v = 0; v < VQ; ++v)
+        for (int64_t f = offsets_q[v]; f < offsets_q[v + 1]; ++f) vq[(size_t)f] = (int32_t)v;
+    for (int64_t v = 0; v < VT; ++v)
+        for (int64_t f = offsets_t[v]; f < offsets_t[v + 1]; ++f) vt[(size_t)f] = (int32_t)v;
+    if (ids_q) {  // frames of videos with equal ids are not compared (a query that is also in the target set)
+        gq.resize((size_t)nq);
+        gt.resize((size_t)nt);
+        for (int64_t f = 0; f < nq; ++f) gq[(size_t)f] = ids_q[vq[(size_t)f]];
+        for (int64_t f = 0; f < nt; ++f) gt[(size_t)f] = ids_t[vt[(size_t)f]];
     }
+    DevBuf d_q, d_t, d_iq, d_it, d_gq, d_gt, d_pairs, d_cnt;
+    size_t bq = 0, bt = 0;
+    if (int rc = hvd_fp4_image_bytes(nq, &bq)) return rc;
+    if (int rc = hvd_fp4_image_bytes(nt, &bt)) return rc;
+    HIP_TRY(d_q.alloc(32 * (size_t)nq));
+    HIP_TRY(d_t.alloc(32 * (size_t)nt));
+    HIP_TRY(d_iq.alloc(bq));
+    HIP_TRY(d_it.alloc(bt));
+    HIP_TRY(hipMemcpyAsync(d_q.p, frames_q, 32 * (size_t)nq, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_t.p, frames_t, 32 * (size_t)nt, hipMemcpyHostToDevice, g.stream));
+    if (int rc = hvd_dev_expand_fp4(d_q.p, nq, d_iq.p)) return rc;
+    if (int rc = hvd_dev_expand_fp4(d_t.p, nt, d_it.p)) return rc;
+    if (ids_q) {
+        HIP_TRY(d_gq.alloc(4 * (size_t)nq));
+        HIP_TRY(d_gt.alloc(4 * (size_t)nt));
+        HIP_TRY(hipMemcpyAsync(d_gq.p, gq.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(d_gt.p, gt.data(), 4 * (size_t)nt, hipMemcpyHostToDevice, g.stream));
+    }
+    HIP_TRY(d_cnt.alloc(8));
+    std::vector<hvd_pair> recs;
+    int64_t fcap = std::max<int64_t>(1 << 16, nq);
+    for (;;) {
+        if (d_pairs.p) {
+            HIP_TRY(hipFree(d_pairs.p));
+            d_pairs.p = nullptr;
+        }
+        HIP_TRY(d_pairs.alloc(sizeof(hvd_pair) * (size_t)fcap));
+        HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 8, g.stream));
+        if (int rc = hvd_dev_cross_hamming256_mfma(d_iq.p, nq, d_it.p, nt, ids_q ? d_gq.p : nullptr,
+                                                   ids_q ? d_gt.p : nullptr, max_dist, 0, 1, d_pairs.p, fcap, d_cnt.p))
+            return rc;
+        unsigned long long cnt = 0;
+        HIP_TRY(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if ((int64_t)cnt > fcap) {
+            fcap = (int64_t)cnt;
+            continue;
+        }
+        recs.resize((size_t)cnt);
+        if (cnt) {
+            HIP_TRY(hipMemcpyAsync(recs.data(), d_pairs.p, sizeof(hvd_pair) * (size_t)cnt, hipMemcpyDeviceToHost,
+                                   g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+        }
+        break;
+    }
+    std::vector<hvd_vmatch> res;
+    aggregate_video_hits(recs, vq.data(), vt.data(), res);
     *out_count = (int64_t)res.size();
     if ((int64_t)res.size() > cap)
         return fail(HVD_ERR_OVERFLOW, "video match buffer too small: need %lld, cap %lld", (long long)res.size(),

@@ -28,6 +28,10 @@ bool allpairs_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32
 uint32_t fp4_rows_padded(uint32_t n);
 hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s);
 hipError_t launch_allpairs_mfma(const AllPairsArgs& a, const void* d_img, hipStream_t s);
+// a.n / a.d_group describe the target set; rows are the nq query hashes (image d_img_q, groups a.d_group
+// for queries and d_group_t for targets; pass both or neither).
+hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
+                             const int32_t* d_group_t, hipStream_t s);
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 
 hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t max_dist,

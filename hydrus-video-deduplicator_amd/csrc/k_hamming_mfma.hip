@@ -113,12 +113,15 @@ __device__ __forceinline__ v16f tile_dot(const v4i (&a)[4], const v4i (&b)[4]) {
 // Rare path: some pair of this 32-candidate panel may be within tolerance. Recompute every
 // query tile of the wave over all 256 bits (A fragments are re-read from memory so that the
 // loop stays rolled and the fast path's registers stay untouched) and append the hits.
+// rect = false: one set, pairs i<j, group[i] != group[j]. rect = true: query set x target set
+// (row index into the query image, column index into the target image), every (i<nq, j<n) pair.
 template <int TILES>
 __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, const uint4* base, uint32_t sw,
                                              uint32_t wrow0, uint32_t j, uint32_t n, uint32_t h, uint32_t li,
                                              const int32_t* __restrict__ group, float thr_full,
                                              hvd_pair* __restrict__ out, unsigned long long cap,
-                                             unsigned long long* __restrict__ count) {
+                                             unsigned long long* __restrict__ count, bool rect, uint32_t nq,
+                                             const int32_t* __restrict__ group_t) {
     v4i bf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) bf[s] = as_v4i(base[(2u * s + h) ^ sw]);
@@ -133,8 +136,8 @@ __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, cons
         for (int r = 0; r < 16; ++r) {
             // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
             const uint32_t i = wrow0 + 32u * t + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h;
-            if (acc[r] >= thr_full && i < j && j < n) {
-                if (group == nullptr || group[i] != group[j])
+            if (acc[r] >= thr_full && j < n && (rect ? i < nq : i < j)) {
+                if (group == nullptr || group[i] != (rect ? group_t[j] : group[j]))
                     append_pair_m(out, cap, count, i, j, (uint32_t)(256 - (int)acc[r]) >> 1);
             }
         }
@@ -157,12 +160,16 @@ __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src,
     }
 }
 
-template <int TILES, bool PREFILTER>
+// RECT = false: img_q == img (one set, strict upper triangle). RECT = true: rows come from the
+// query image img_q (nq hashes), candidates from the target image img (n hashes), full rectangle.
+template <int TILES, bool PREFILTER, bool RECT>
 __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
                                                           const int32_t* __restrict__ group, uint32_t max_dist,
                                                           uint32_t col_chunk, uint32_t rank, uint32_t world,
                                                           hvd_pair* __restrict__ out, unsigned long long cap,
-                                                          unsigned long long* __restrict__ count) {
+                                                          unsigned long long* __restrict__ count,
+                                                          const uint4* __restrict__ img_q, uint32_t nq,
+                                                          const int32_t* __restrict__ group_t) {
     constexpr uint32_t WROWS = 32u * TILES, ROWS = 4u * WROWS;
     constexpr int NB = PREFILTER ? 2 : 4;
     __shared__ uint4 lds[2][kSuper * 8];
@@ -171,8 +178,9 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     const uint32_t row0 = rb * ROWS;
     const uint32_t col0 = cb * col_chunk;
     const uint32_t col1 = min(col0 + col_chunk, n_pad);
-    if (min(col1, n) <= row0 + 1u) return;  // tile entirely on/below the diagonal
+    if (!RECT && min(col1, n) <= row0 + 1u) return;  // tile entirely on/below the diagonal
     if (world > 1u && (rb + cb) % world != rank) return;
+    const uint4* __restrict__ imgq = RECT ? img_q : img;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, li = lane & 31u, h = lane >> 5;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     for (int t = 0; t < TILES; ++t) {
         const uint32_t hash = wrow0 + 32u * t + li;  // < n_pad by construction
 #pragma unroll
-        for (int s = 0; s < NB; ++s) a[t][s] = as_v4i(img[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
+        for (int s = 0; s < NB; ++s) a[t][s] = as_v4i(imgq[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
     }
 
     const float thr_full = 256.0f - 2.0f * (float)max_dist;                       // > 0 (host guarantees)
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     const int thr_bits = thr_fast > 0.0f ? __float_as_int(thr_fast) : (int)0x80000000;  // panel takes the slow path
 
     // candidates <= row0 cannot pair with rows >= row0 (i<j): start at the super-panel holding row0+1
-    const uint32_t j0 = max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
+    const uint32_t j0 = RECT ? col0 : max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
     const uint32_t nsp = (col1 - j0) / kSuper;  // col0, col1, j0 are multiples of kSuper
 
     stage_super_panel(img + (size_t)j0 * 8u, &lds[0][0], wave, lane);
@@ -226,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
             mm = max(mm, max16_bits(cur));
 
             if (__builtin_expect(__any(mm >= thr_bits), 0))
-                panel_slow_path<TILES>(img, base, sw, wrow0, jsp + cl, n, h, li, group, thr_full, out, cap, count);
+                panel_slow_path<TILES>(imgq, base, sw, wrow0, jsp + cl, n, h, li, group, thr_full, out, cap, count,
+                                       RECT, nq, group_t);
         }
 
         __syncthreads();  // (hipcc drains the in-flight global->LDS loads with vmcnt(0) first)
@@ -283,9 +292,39 @@ static hipError_t launch_mfma_t(const AllPairsArgs& a, const void* d_img, hipStr
     constexpr uint32_t ROWS = 128u * T;
     const uint32_t chunk = pick_col_chunk_m(n_pad, ROWS);
     dim3 grid((a.n + ROWS - 1) / ROWS, (n_pad + chunk - 1) / chunk);
-    hipLaunchKernelGGL((k_allpairs_mfma<T, PF>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad, a.d_group,
-                       a.max_dist, chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count);
+    hipLaunchKernelGGL((k_allpairs_mfma<T, PF, false>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+                       a.d_group, a.max_dist, chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count,
+                       (const uint4*)nullptr, 0u, (const int32_t*)nullptr);
     return hipGetLastError();
+}
+
+// Query set (nq hashes, image d_img_q) x target set (a.n hashes, image d_img_t): full rectangle.
+template <int T, bool PF>
+static hipError_t launch_cross_t(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
+                                 const int32_t* d_group_t, hipStream_t s) {
+    const uint32_t n_pad = fp4_rows_padded(a.n);
+    constexpr uint32_t ROWS = 128u * T;
+    // column chunk sized for the rectangle: enough tiles to fill the chip even when nq is small
+    uint64_t n_rb = (nq + ROWS - 1) / ROWS;
+    uint64_t want_cb = (4096 + n_rb - 1) / n_rb;
+    uint64_t chunk = (n_pad + want_cb - 1) / want_cb;
+    if (chunk < 256) chunk = 256;
+    if (chunk > 4096) chunk = 4096;
+    chunk = (chunk + kSuper - 1) / kSuper * kSuper;
+    if ((n_pad + chunk - 1) / chunk > 65535u) chunk = round_up((n_pad + 65534u) / 65535u, kSuper);
+    dim3 grid((unsigned)n_rb, (unsigned)((n_pad + chunk - 1) / chunk));
+    hipLaunchKernelGGL((k_allpairs_mfma<T, PF, true>), grid, dim3(256), 0, s, (const uint4*)d_img_t, a.n, n_pad,
+                       a.d_group, a.max_dist, (uint32_t)chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count,
+                       (const uint4*)d_img_q, nq, d_group_t);
+    return hipGetLastError();
+}
+
+hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
+                             const int32_t* d_group_t, hipStream_t s) {
+    if (nq == 0 || a.n == 0) return hipSuccess;
+    if (a.max_dist >= 128u) return hipErrorInvalidValue;  // sign trick needs a positive threshold
+    if (a.max_dist >= 64u) return launch_cross_t<8, false>(a, d_img_q, nq, d_img_t, d_group_t, s);
+    return launch_cross_t<8, true>(a, d_img_q, nq, d_img_t, d_group_t, s);
 }
 
 hipError_t launch_allpairs_mfma(const AllPairsArgs& a_in, const void* d_img, hipStream_t s) {

@@ -80,6 +80,43 @@ def match_videos(frames: np.ndarray, offsets: np.ndarray, max_dist: int = DISTAN
         return out[: cnt.value].copy()
 
 
+def match_videos_cross(frames_q: np.ndarray, offsets_q: np.ndarray, frames_t: np.ndarray, offsets_t: np.ndarray,
+                       ids_q: np.ndarray | None = None, ids_t: np.ndarray | None = None,
+                       max_dist: int = DISTANCE_TOLERANCE, cap: int | None = None) -> np.ndarray:
+    """Query videos x target videos (batch form of VpTreeManager.search_file, db/vptree.py:865-902):
+    VMATCH_DTYPE records (a = query index, b = target index) with >= 1 frame hit, sorted by (a, b).
+    ids_q/ids_t (int32 per video): equal ids are never compared (a query that is in the target set)."""
+    frames_q = np.ascontiguousarray(frames_q, dtype=np.uint8).reshape(-1, 32)
+    frames_t = np.ascontiguousarray(frames_t, dtype=np.uint8).reshape(-1, 32)
+    offsets_q = np.ascontiguousarray(offsets_q, dtype=np.int64)
+    offsets_t = np.ascontiguousarray(offsets_t, dtype=np.int64)
+    VQ, VT = offsets_q.size - 1, offsets_t.size - 1
+    if offsets_q[-1] != frames_q.shape[0] or offsets_t[-1] != frames_t.shape[0]:
+        raise ValueError("offsets[-1] must equal the number of frame hashes")
+    if (ids_q is None) != (ids_t is None):
+        raise ValueError("pass both id arrays or neither")
+    if ids_q is not None:
+        ids_q = np.ascontiguousarray(ids_q, dtype=np.int32)
+        ids_t = np.ascontiguousarray(ids_t, dtype=np.int32)
+        if ids_q.shape != (VQ,) or ids_t.shape != (VT,):
+            raise ValueError("one id per video")
+    lib = _lib.ensure()
+    cap = max(1024, VQ) if cap is None else int(cap)
+    while True:
+        out = np.zeros(max(cap, 1), dtype=VMATCH_DTYPE)
+        cnt = C.c_int64(0)
+        rc = lib.hvd_vpdq_match_videos_cross(
+            frames_q.ctypes.data if frames_q.size else None, offsets_q.ctypes.data, VQ,
+            ids_q.ctypes.data if ids_q is not None else None,
+            frames_t.ctypes.data if frames_t.size else None, offsets_t.ctypes.data, VT,
+            ids_t.ctypes.data if ids_t is not None else None, int(max_dist), out.ctypes.data, cap, C.byref(cnt))
+        if rc == _lib.HVD_ERR_OVERFLOW:
+            cap = int(cnt.value)
+            continue
+        _lib.check(rc)
+        return out[: cnt.value].copy()
+
+
 def similarity_of_records(records: np.ndarray, lengths: np.ndarray, policy: str | None = None) -> np.ndarray:
     """Per-record similarity in [0,100] under the match policy, taking the better of the two
     search directions (the reference finds {A,B} from A's search or from B's)."""

@@ -100,6 +100,16 @@ int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, in
 int hvd_vpdq_match_videos(const uint8_t* frames, const int64_t* offsets, int64_t V, int max_dist, hvd_vmatch* out,
                           int64_t cap, int64_t* out_count);
 
+/* Query-set x target-set form of the same search: the steady-state workload after the first
+ * run (new videos against the existing library; semantics of VpTreeManager.search_file,
+ * db/vptree.py:865-902, for a batch of files). out: every (a = query video, b = target video)
+ * with >=1 frame hit; q_hits counts frames of the query video, t_hits frames of the target.
+ * ids_q / ids_t (both or neither): videos with equal ids are not compared with each other (a
+ * query that is itself in the target set must not match itself). max_dist in [0,127]. */
+int hvd_vpdq_match_videos_cross(const uint8_t* frames_q, const int64_t* offsets_q, int64_t VQ, const int32_t* ids_q,
+                                const uint8_t* frames_t, const int64_t* offsets_t, int64_t VT, const int32_t* ids_t,
+                                int max_dist, hvd_vmatch* out, int64_t cap, int64_t* out_count);
+
 /* --------------------------------------------- device-resident API ------- */
 /* For pipelines that keep data in HBM (hash on the GPU, then search) and for the
  * benchmark. Pointers named d_* are device pointers from hvd_dev_malloc. Kernels are
@@ -139,6 +149,13 @@ int hvd_fp4_image_bytes(int64_t n, size_t* out_bytes);
 int hvd_dev_expand_fp4(const void* d_db, int64_t n, void* d_img);
 int hvd_dev_allpairs_hamming256_mfma(const void* d_db, const void* d_img, int64_t n, const void* d_group, int max_dist, int rank,
                                      int world, void* d_pairs, int64_t cap, void* d_count, int variant);
+
+/* Rectangular form on two FP4 images (nq query hashes x nt target hashes): appends (i = query
+ * row, j = target row, dist). d_group_q / d_group_t (both or neither): pairs with equal group
+ * values are dropped. max_dist in [0,127]. */
+int hvd_dev_cross_hamming256_mfma(const void* d_img_q, int64_t nq, const void* d_img_t, int64_t nt,
+                                  const void* d_group_q, const void* d_group_t, int max_dist, int rank, int world,
+                                  void* d_pairs, int64_t cap, void* d_count);
 
 /* Host-only: the tile geometry hvd_dev_allpairs_hamming256 uses for (n, variant): a
  * tile is rows [rb*rows_per_block, +rows_per_block) x columns [cb*col_chunk, +col_chunk). */
