@@ -42,6 +42,11 @@ SIGNATURES = {
     "hvd_vpdq_match_videos": (_int, [_vp, _vp, _i64, _int, _vp, _i64, C.POINTER(_i64)]),
     "hvd_vpdq_match_videos_cross": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _int, _vp, _i64,
                                            C.POINTER(_i64)]),
+    "hvd_hasher_create": (_int, [_int, _int, _int, _i64, C.POINTER(_vp)]),
+    "hvd_hasher_push": (_int, [_vp, _vp]),
+    "hvd_hasher_pending": (_int, [_vp, C.POINTER(_i64)]),
+    "hvd_hasher_finish": (_int, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "hvd_hasher_destroy": (_int, [_vp]),
     "hvd_dev_malloc": (_int, [C.POINTER(_vp), _sz]),
     "hvd_dev_free": (_int, [_vp]),
     "hvd_dev_memset": (_int, [_vp, _int, _sz]),

@@ -92,6 +92,17 @@ bool pair_less(const hvd_pair& x, const hvd_pair& y) { return x.i != y.i ? x.i <
 
 static void free_exchange_buffers();
 
+namespace hvd {
+int api_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+const float* api_dct_device() { return g.ready ? g.d_dct : nullptr; }
+}  // namespace hvd
+
 extern "C" {
 
 int hvd_abi_version(void) { return HVD_ABI_VERSION; }
@@ -249,28 +260,45 @@ int hvd_pdq_scratch_bytes(int64_t n, int h, int w, int channels, size_t* out_byt
     return HVD_OK;
 }
 
+}  // extern "C" (the helpers below have C++ linkage; hvd_stream.cpp uses them)
+
+namespace hvd {
+size_t api_scratch_bytes(int64_t n, int h, int w, int channels) {
+    size_t b = 0;
+    (void)hvd_pdq_scratch_bytes(n, h, w, channels, &b);
+    return b;
+}
+
+// Enqueue the PDQ kernels for one batch on stream s (geometry already validated).
+hipError_t api_launch_hash(const void* d_frames, int64_t n, int h, int w, int channels, void* d_scratch, void* d_hashes,
+                           void* d_quality, hipStream_t s) {
+    if (h == 64 && w == 64 && channels == 1)
+        return launch_pdq_hash64(d_frames, 0, n, g.d_dct, (uint8_t*)d_hashes, (int32_t*)d_quality, s);
+    hipError_t e;
+    float* out64 = (float*)d_scratch;
+    if (h == 64 && w == 64)
+        e = launch_pdq_luma64_rgb((const uint8_t*)d_frames, n, out64, s);
+    else
+        e = launch_pdq_downsample((const uint8_t*)d_frames, n, h, w, channels, out64 + (size_t)n * 4096, out64, s);
+    if (e != hipSuccess) return e;
+    return launch_pdq_hash64(d_scratch, 1, n, g.d_dct, (uint8_t*)d_hashes, (int32_t*)d_quality, s);
+}
+}  // namespace hvd
+
+extern "C" {
+
 int hvd_dev_pdq_hash_frames(const void* d_frames, int64_t n, int h, int w, int channels, void* d_scratch,
                             void* d_hashes, void* d_quality) {
     if (int rc = need_ready()) return rc;
     if (n < 0 || h < 64 || w < 64 || (channels != 1 && channels != 3))
         return fail(HVD_ERR_ARG, "bad frame geometry n=%lld h=%d w=%d channels=%d (need h,w >= 64)", (long long)n, h,
                     w, channels);
+    if (h > 4096 || w > 4096) return fail(HVD_ERR_ARG, "frames larger than 4096 px per side are not supported");
     if (n == 0) return HVD_OK;
     if (!d_frames || !d_hashes || !d_quality) return fail(HVD_ERR_ARG, "NULL device pointer");
-    if (h == 64 && w == 64 && channels == 1) {
-        HIP_TRY(hvd::launch_pdq_hash64(d_frames, 0, n, g.d_dct, (uint8_t*)d_hashes, (int32_t*)d_quality, g.stream));
-        return HVD_OK;
-    }
-    if (!d_scratch) return fail(HVD_ERR_ARG, "d_scratch (hvd_pdq_scratch_bytes) is required unless 64x64 gray");
-    if (h == 64 && w == 64) {
-        HIP_TRY(hvd::launch_pdq_luma64_rgb((const uint8_t*)d_frames, n, (float*)d_scratch, g.stream));
-    } else {
-        if (h > 4096 || w > 4096) return fail(HVD_ERR_ARG, "frames larger than 4096 px per side are not supported");
-        float* out64 = (float*)d_scratch;
-        HIP_TRY(hvd::launch_pdq_downsample((const uint8_t*)d_frames, n, h, w, channels, out64 + (size_t)n * 4096, out64,
-                                           g.stream));
-    }
-    HIP_TRY(hvd::launch_pdq_hash64(d_scratch, 1, n, g.d_dct, (uint8_t*)d_hashes, (int32_t*)d_quality, g.stream));
+    const bool need_scratch = !(h == 64 && w == 64 && channels == 1);
+    if (need_scratch && !d_scratch) return fail(HVD_ERR_ARG, "d_scratch (hvd_pdq_scratch_bytes) is required unless 64x64 gray");
+    HIP_TRY(hvd::api_launch_hash(d_frames, n, h, w, channels, d_scratch, d_hashes, d_quality, g.stream));
     return HVD_OK;
 }
 

@@ -1,0 +1,192 @@
+// hvd_stream.cpp -- streaming frame hasher behind vpdq.VideoHasher (reference
+// vpdqpy/vpdqpy.py:113-119): a decoder thread pushes frames one at a time; frames are
+// staged in a ring of pinned batch slots; every slot owns a HIP stream on which its batch is
+// uploaded (async H2D), hashed (PDQ kernels) and its 36 bytes per frame downloaded. Uploading
+// batch k+1 overlaps hashing batch k; push() blocks only when every slot is still in flight,
+// which bounds the staging memory like the reference's blocking frame queue
+// (vpdqpy.py:115-117).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "hvd_kernels.h"
+
+namespace hvd {
+int api_fail(int code, const char* fmt, ...);     // hvd_api.cpp
+const float* api_dct_device();                    // hvd_api.cpp; nullptr before hvd_init
+size_t api_scratch_bytes(int64_t n, int h, int w, int channels);
+hipError_t api_launch_hash(const void* d_frames, int64_t n, int h, int w, int channels, void* d_scratch, void* d_hashes,
+                           void* d_quality, hipStream_t s);
+}  // namespace hvd
+
+namespace {
+
+constexpr int kSlots = 3;
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    uint8_t* h_frames = nullptr;   // pinned
+    uint8_t* h_hashes = nullptr;   // pinned
+    int32_t* h_quality = nullptr;  // pinned
+    void* d_frames = nullptr;
+    void* d_scratch = nullptr;
+    void* d_hashes = nullptr;
+    void* d_quality = nullptr;
+    int64_t filled = 0;    // frames staged in h_frames
+    int64_t in_flight = 0; // frames submitted and not yet collected
+};
+
+}  // namespace
+
+struct hvd_hasher {
+    int w = 0, h = 0, channels = 0;
+    int64_t batch = 0;
+    size_t frame_bytes = 0;
+    Slot slot[kSlots];
+    int cur = 0;
+    std::vector<uint8_t> hashes;   // collected results, frame order
+    std::vector<int32_t> quality;
+    bool failed = false;
+};
+
+#define S_TRY(expr)                                                                                        \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return hvd::api_fail(HVD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+static int collect(hvd_hasher* hs, Slot& s) {
+    if (s.in_flight == 0) return HVD_OK;
+    S_TRY(hipEventSynchronize(s.done));
+    hs->hashes.insert(hs->hashes.end(), s.h_hashes, s.h_hashes + 32 * s.in_flight);
+    hs->quality.insert(hs->quality.end(), s.h_quality, s.h_quality + s.in_flight);
+    s.in_flight = 0;
+    return HVD_OK;
+}
+
+static int submit(hvd_hasher* hs, Slot& s) {
+    if (s.filled == 0) return HVD_OK;
+    const int64_t m = s.filled;
+    S_TRY(hipMemcpyAsync(s.d_frames, s.h_frames, hs->frame_bytes * (size_t)m, hipMemcpyHostToDevice, s.stream));
+    S_TRY(hvd::api_launch_hash(s.d_frames, m, hs->h, hs->w, hs->channels, s.d_scratch, s.d_hashes, s.d_quality, s.stream));
+    S_TRY(hipMemcpyAsync(s.h_hashes, s.d_hashes, 32 * (size_t)m, hipMemcpyDeviceToHost, s.stream));
+    S_TRY(hipMemcpyAsync(s.h_quality, s.d_quality, 4 * (size_t)m, hipMemcpyDeviceToHost, s.stream));
+    S_TRY(hipEventRecord(s.done, s.stream));
+    s.in_flight = m;
+    s.filled = 0;
+    return HVD_OK;
+}
+
+extern "C" {
+
+int hvd_hasher_destroy(hvd_hasher* hs) {
+    if (!hs) return HVD_OK;
+    for (Slot& s : hs->slot) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.h_frames) (void)hipHostFree(s.h_frames);
+        if (s.h_hashes) (void)hipHostFree(s.h_hashes);
+        if (s.h_quality) (void)hipHostFree(s.h_quality);
+        if (s.d_frames) (void)hipFree(s.d_frames);
+        if (s.d_scratch) (void)hipFree(s.d_scratch);
+        if (s.d_hashes) (void)hipFree(s.d_hashes);
+        if (s.d_quality) (void)hipFree(s.d_quality);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete hs;
+    return HVD_OK;
+}
+
+int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames, hvd_hasher** out) {
+    if (!out) return hvd::api_fail(HVD_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!hvd::api_dct_device()) return hvd::api_fail(HVD_ERR_STATE, "hvd_init() has not been called (no CPU fallback exists)");
+    if (width < 64 || height < 64 || width > 4096 || height > 4096 || (channels != 1 && channels != 3) || batch_frames < 1)
+        return hvd::api_fail(HVD_ERR_ARG, "bad hasher geometry %dx%dx%d batch %lld", width, height, channels,
+                             (long long)batch_frames);
+    hvd_hasher* hs = new hvd_hasher();
+    hs->w = width;
+    hs->h = height;
+    hs->channels = channels;
+    hs->batch = batch_frames;
+    hs->frame_bytes = (size_t)width * height * channels;
+    const size_t scratch = hvd::api_scratch_bytes(batch_frames, height, width, channels);
+    for (Slot& s : hs->slot) {
+        hipError_t e = hipSuccess;
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_frames, hs->frame_bytes * (size_t)batch_frames, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_hashes, 32 * (size_t)batch_frames, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_quality, 4 * (size_t)batch_frames, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&s.d_frames, hs->frame_bytes * (size_t)batch_frames);
+        if (e == hipSuccess && scratch) e = hipMalloc(&s.d_scratch, scratch);
+        if (e == hipSuccess) e = hipMalloc(&s.d_hashes, 32 * (size_t)batch_frames);
+        if (e == hipSuccess) e = hipMalloc(&s.d_quality, 4 * (size_t)batch_frames);
+        if (e != hipSuccess) {
+            hvd_hasher_destroy(hs);
+            return hvd::api_fail(HVD_ERR_HIP, "hasher allocation: %s", hipGetErrorString(e));
+        }
+    }
+    *out = hs;
+    return HVD_OK;
+}
+
+/* Copies one frame (width*height*channels bytes) into the ring. Blocks only when the next
+ * slot's previous batch is still being hashed. The caller's buffer is not kept. */
+int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame) {
+    if (!hs || !frame) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/frame");
+    Slot& s = hs->slot[hs->cur];
+    if (s.filled == 0 && s.in_flight) {  // slot being reused: its previous batch must have landed
+        if (int rc = collect(hs, s)) return rc;
+    }
+    memcpy(s.h_frames + hs->frame_bytes * (size_t)s.filled, frame, hs->frame_bytes);
+    if (++s.filled == hs->batch) {
+        if (int rc = submit(hs, s)) return rc;
+        hs->cur = (hs->cur + 1) % kSlots;
+    }
+    return HVD_OK;
+}
+
+/* Flushes the partial batch, waits for everything, returns all hashes / qualities in push
+ * order (no quality filtering: that is VideoHasher.finish's policy, vpdqpy.py:119). The hasher
+ * is empty afterwards and can be reused for the next video. */
+int hvd_hasher_finish(hvd_hasher* hs, uint8_t* out_hashes, int32_t* out_quality, int64_t cap, int64_t* out_n) {
+    if (!hs || !out_n) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/out_n");
+    // Slots were submitted in ring order; collect oldest-first so that results stay in frame order.
+    Slot& c = hs->slot[hs->cur];
+    const bool partial = c.filled > 0;
+    for (int k = 1; k <= kSlots; ++k) {
+        Slot& s = hs->slot[(hs->cur + k) % kSlots];
+        if (&s == &c && partial) {
+            // the current slot may still hold an older in-flight batch only if filled == 0; here it has
+            // staged frames, so any older batch of it was collected in push()
+            if (int rc = submit(hs, s)) return rc;
+        }
+        if (int rc = collect(hs, s)) return rc;
+    }
+    const int64_t n = (int64_t)hs->quality.size();
+    *out_n = n;
+    if (n > cap) return hvd::api_fail(HVD_ERR_OVERFLOW, "need room for %lld frames, cap %lld", (long long)n, (long long)cap);
+    if (n) {
+        if (!out_hashes || !out_quality) return hvd::api_fail(HVD_ERR_ARG, "NULL output");
+        memcpy(out_hashes, hs->hashes.data(), 32 * (size_t)n);
+        memcpy(out_quality, hs->quality.data(), 4 * (size_t)n);
+    }
+    hs->hashes.clear();
+    hs->quality.clear();
+    hs->cur = 0;
+    return HVD_OK;
+}
+
+int hvd_hasher_pending(hvd_hasher* hs, int64_t* out_frames) {
+    if (!hs || !out_frames) return hvd::api_fail(HVD_ERR_ARG, "NULL");
+    int64_t n = (int64_t)hs->quality.size();
+    for (Slot& s : hs->slot) n += s.filled + s.in_flight;
+    *out_frames = n;
+    return HVD_OK;
+}
+
+}  // extern "C"

