@@ -258,13 +258,15 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
     return hipGetLastError();
 }
 
+uint32_t g_mfma_col_chunk_max = 8192;  // tuning knob (hvd_debug_set "mfma_col_chunk_max"); 2048..32768 within 3 %
+
 static uint32_t pick_col_chunk_m(uint32_t n_pad, uint32_t rows_per_wg) {
     uint64_t n_rb = (n_pad + rows_per_wg - 1) / rows_per_wg;
     uint64_t want_cb = (8192 + n_rb - 1) / n_rb;
     if (want_cb < 1) want_cb = 1;
     uint64_t chunk = (n_pad + want_cb - 1) / want_cb;
     if (chunk < 256) chunk = 256;
-    if (chunk > 4096) chunk = 4096;
+    if (chunk > g_mfma_col_chunk_max) chunk = g_mfma_col_chunk_max;
     chunk = (chunk + kSuper - 1) / kSuper * kSuper;
     if ((n_pad + chunk - 1) / chunk > 65535u) chunk = round_up((n_pad + 65534u) / 65535u, kSuper);
     return (uint32_t)chunk;

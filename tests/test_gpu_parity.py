@@ -449,3 +449,22 @@ def test_streaming_hasher_ring(gpu, hvd, oracle, geom):
             assert got.value == 23 and np.array_equal(hh, ho[:23]) and np.array_equal(qq, qo[:23])
     finally:
         lib.hvd_hasher_destroy(hdl)
+
+
+def test_k2_full_size_10m_sharded_8_ways(gpu, hvd):
+    """BASELINE config 4 (10M hashes, ~5e13 comparisons, 8 ranks): the 8 ranks' tile sets are run
+    one after the other on this GPU; the union must contain every planted pair within tolerance
+    with its exact distance, ranks must be disjoint and balanced, every record must verify."""
+    n, world = 10_000_000, 8
+    db, planted = hvd.synth.hash_db(n, seed=4)
+    d_db = gpu.DeviceBuffer.from_array(db)
+    parts = [hvd.multigpu.sharded_allpairs(d_db.ptr, n, r, world, None) for r in range(world)]
+    got = hvd.multigpu.merge_pairs(parts)  # raises if two ranks report the same pair
+    x = np.unpackbits(db[got["i"]] ^ db[got["j"]], axis=1).sum(1)
+    assert np.array_equal(x, got["dist"]) and (got["dist"] <= 31).all() and (got["i"] < got["j"]).all()
+    d_pl = np.unpackbits(db[planted[:, 0]] ^ db[planted[:, 1]], axis=1).sum(1)
+    want = {(int(min(s, d)), int(max(s, d))) for (s, d, _), dd in zip(planted, d_pl) if dd <= 31}
+    found = set(zip(got["i"].tolist(), got["j"].tolist()))
+    assert want <= found and len(found) - len(want) <= len(want) // 10 + 5
+    sizes = [len(p) for p in parts]
+    assert min(sizes) > 0.5 * max(sizes), sizes  # planted pairs are uniform over the triangle
