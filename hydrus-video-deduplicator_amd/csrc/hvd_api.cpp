@@ -239,6 +239,10 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_pdq_dct_from_lds = value != 0;
         return HVD_OK;
     }
+    if (strcmp(key, "pdq_luma_lut") == 0) {
+        hvd::g_pdq_luma_lut = value;
+        return HVD_OK;
+    }
     if (strcmp(key, "mfma_col_chunk_max") == 0) {
         if (value < 256 || value % 128) return fail(HVD_ERR_ARG, "mfma_col_chunk_max must be a multiple of 128, >= 256");
         hvd::g_mfma_col_chunk_max = (uint32_t)value;

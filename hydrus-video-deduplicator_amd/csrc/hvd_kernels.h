@@ -42,6 +42,7 @@ hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_
 // kind 0: gray u8 64x64 frames; kind 1: float 64x64 buffers (output of the
 // down-sampler). d_in strides are implied by kind.
 extern bool g_pdq_dct_from_lds;
+extern int g_pdq_luma_lut;
 extern bool g_pdq_fused_down512;
 hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
                              int32_t* d_quality, hipStream_t s);

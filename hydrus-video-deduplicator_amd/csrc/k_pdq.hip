@@ -71,7 +71,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {  // exact: integer-valu
 // KIND 0: uint8 gray 64x64 frames. KIND 1: float 64x64 buffers (down-sampler output).
 // DLDS: stage 1 takes D[i][k] from LDS broadcast reads (VGPR operands, full-rate v_mul) instead of
 // scalar loads (SGPR operands: v_mul_f32 s,v issues at half rate, profiles/r01_ubench_valu.txt).
-template <int KIND, bool DLDS>
+template <int KIND, bool DLDS, int LUT>
 __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in, long long n,
                                                     const float* __restrict__ dct, uint8_t* __restrict__ hashes,
                                                     int32_t* __restrict__ quality) {
@@ -95,7 +95,14 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             if (KIND == 0) {
                 const uint8_t* src = reinterpret_cast<const uint8_t*>(in) + f * 4096 + lane;
 #pragma unroll
-                for (int k = 0; k < 64; ++k) a[k] = lds.luma_lut[src[k * 64]];
+                for (int k = 0; k < 64; ++k) {
+                    if (LUT == 0) {
+                        a[k] = luma_gray(src[k * 64]);
+                    } else {
+                        a[k] = lds.luma_lut[src[k * 64]];
+                        if (LUT == 2 && (k & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight
+                    }
+                }
             } else {
                 const float* src = reinterpret_cast<const float*>(in) + f * 4096 + lane;
 #pragma unroll
@@ -111,6 +118,8 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
                 const float right = __shfl_down(a[k], 1, 64);
                 const float t = grad_term(a[k], right);
                 gs += (lane < 63) ? t : 0.0f;
+                // keep the scheduler from hoisting all 64 cross-lane reads (64 extra live VGPRs)
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
             const int gsum = (int)wave_sum_f32(gs);
             int qual = gsum / 90;
@@ -580,6 +589,7 @@ __global__ __launch_bounds__(512, 4) void k_down512(  // 4 waves/SIMD = 2 workgr
 
 namespace hvd {
 
+int g_pdq_luma_lut = 1;           // 0: compute luma, 1: LDS table, 2: LDS table, loads in groups of 16
 bool g_pdq_dct_from_lds = false;  // A/B switch (hvd_debug_set): stage-1 DCT operand from LDS vs SGPR; measured equal
 
 hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
@@ -589,14 +599,17 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
     const int64_t max_grid = 256 * 7;  // 7 workgroups/CU fit by LDS (21.8 KB each)
     dim3 grid((unsigned)(groups < max_grid ? groups : max_grid));
     const bool dlds = g_pdq_dct_from_lds;
-    if (kind == 0 && dlds)
-        hipLaunchKernelGGL((k_pdq_hash64<0, true>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
-    else if (kind == 0)
-        hipLaunchKernelGGL((k_pdq_hash64<0, false>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
-    else if (dlds)
-        hipLaunchKernelGGL((k_pdq_hash64<1, true>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
-    else
-        hipLaunchKernelGGL((k_pdq_hash64<1, false>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+    const int lut = g_pdq_luma_lut;
+#define HVD_K1(KIND, D, L) hipLaunchKernelGGL((k_pdq_hash64<KIND, D, L>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality)
+    if (kind == 0) {
+        if (dlds) HVD_K1(0, true, 1);
+        else if (lut == 0) HVD_K1(0, false, 0);
+        else if (lut == 1) HVD_K1(0, false, 1);
+        else HVD_K1(0, false, 2);
+    } else {
+        if (dlds) HVD_K1(1, true, 0); else HVD_K1(1, false, 0);
+    }
+#undef HVD_K1
     return hipGetLastError();
 }
 
