@@ -63,7 +63,13 @@ def main():
     from hvd_amd import multigpu as M
     from hvd_amd import search, synth
 
-    lib = L.init(int(os.environ.get("HVD_FORCE_DEVICE", local_rank)))  # HVD_FORCE_DEVICE: dev testing only
+    ndev = L.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # one process per GPU: LOCAL_RANK picks the device; if the launcher masks devices per rank
+    # (HIP_VISIBLE_DEVICES), every rank sees a single device 0. HVD_FORCE_DEVICE: dev testing only.
+    dev = int(os.environ.get("HVD_FORCE_DEVICE", local_rank if local_rank < ndev else local_rank % ndev))
+    lib = L.init(dev)
 
     dist = None
     exchange = None

@@ -81,8 +81,6 @@ __device__ __forceinline__ void append_pair(hvd_pair* out, unsigned long long ca
     }
 }
 
-__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
-
 // Compare U consecutive candidates (j..j+U-1, wave-uniform, scalar-loaded) against
 // the R query rows of every lane. PREFILTER: look at the first 128 bits first and
 // skip the second half when no lane of the wave can still reach max_dist (exact: a
