@@ -248,6 +248,10 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_mfma_col_chunk_max = (uint32_t)value;
         return HVD_OK;
     }
+    if (strcmp(key, "pdq_down512_systolic") == 0) {
+        hvd::g_pdq_down512_systolic = value != 0;
+        return HVD_OK;
+    }
     if (strcmp(key, "pdq_fused_down512") == 0) {
         hvd::g_pdq_fused_down512 = value != 0;
         return HVD_OK;

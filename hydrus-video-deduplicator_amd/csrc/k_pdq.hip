@@ -585,6 +585,267 @@ __global__ __launch_bounds__(512, 4) void k_down512(  // 4 waves/SIMD = 2 workgr
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// k_down512s: systolic form of the fused 512x512 down-sampler.
+//
+// k_down512 serialises the column recurrence of each strip on one wave. Here every filter
+// output is stored at the index of the STEP that produced it ("label" = true index + 2: the
+// running-sum filter's output lags its input by 2), which makes all four passes tile-aligned:
+// tile (r, c) = label rows [64r, 64r+64) x label columns [32c, 32c+32), r = 0..8, c = 0..16
+// (row band 8 / column 16 hold only the two tail labels 512, 513). For a tile:
+//   A  lane = input row,    32 steps along the row   -> X[row][col]   (state: registers, per band)
+//   B  lane = label column, 64 steps down the rows   -> X in place    (state: from the band above)
+//   C  lane = label row,    32 steps along the row   -> Z[sample][row] (state: registers, per band)
+//   D  lane = sample column, 64 steps down the rows  -> out64          (state: from the band above)
+// Wave r owns row band r for the whole frame and walks c = 0..16; B/D state moves from wave
+// r-1 to wave r through an LDS mailbox, so wave r runs one tile column behind wave r-1
+// (global step t: wave r works on c = t - r). B (lanes 0..31) and D of the previous tile column
+// (lanes 32..35) share one instruction stream. One workgroup barrier per step (26 per frame);
+// X and Z are wave-private. Operation order per filter is upstream's box1DFloat, so the result
+// is bit-identical to k_down512, the generic path and the oracle.
+constexpr int kTR = 64, kTC = 32, kNW = 9;
+
+struct Run5 {
+    float sum, l0, l1, l2, l3;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define HVD_RUN_STEP(X_, L_)                 \
+    st.sum = __fadd_rn(st.sum, (X_));        \
+    st.sum = __fsub_rn(st.sum, (L_));        \
+    (L_) = (X_);
+
+// 64 steady-state steps down a column (every step adds the new value and drops the one four
+// steps back). Every lane stores its output in place; lanes with emit = true also write the
+// decimation samples (label row a multiple of 8) to dst[(i0 + q/8) * 64 + j].
+__device__ __forceinline__ void colpass64_steady(float* p, const int stride, Run5& st, const bool emit,
+                                                 float* __restrict__ dst, const int i0, const int j) {
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = p[e * stride];
+#define HVD_RUN_CHUNK(V, Q0)                                                                       \
+    {                                                                                              \
+        float o[8];                                                                                \
+        HVD_RUN_STEP(V[0], st.l0) o[0] = st.sum; HVD_RUN_STEP(V[1], st.l1) o[1] = st.sum;          \
+        HVD_RUN_STEP(V[2], st.l2) o[2] = st.sum; HVD_RUN_STEP(V[3], st.l3) o[3] = st.sum;          \
+        HVD_RUN_STEP(V[4], st.l0) o[4] = st.sum; HVD_RUN_STEP(V[5], st.l1) o[5] = st.sum;          \
+        HVD_RUN_STEP(V[6], st.l2) o[6] = st.sum; HVD_RUN_STEP(V[7], st.l3) o[7] = st.sum;          \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) p[((Q0) + e) * stride] = __fmul_rn(o[e], 0.25f); \
+        if (emit) dst[(i0 + ((Q0) >> 3)) * 64 + j] = __fmul_rn(o[0], 0.25f);                       \
+    }
+#pragma unroll 1
+    for (int q0 = 0; q0 < 64; q0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = p[(q0 + 8 + e) * stride];
+        HVD_RUN_CHUNK(a, q0)
+        if (q0 + 16 < 64) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = p[(q0 + 16 + e) * stride];
+        }
+        HVD_RUN_CHUNK(b, q0 + 8)
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(kNW * 64) void k_down512s(const uint8_t* __restrict__ frames, long long n,
+                                                       float* __restrict__ out64) {
+    __shared__ float X[kNW][kTR][kTC + 1];       // wave-private tile: A output, then B output in place
+    __shared__ float Z[kNW][2][4][kTR + 1];      // wave-private decimation-column samples of C, double buffered
+    __shared__ float mbB[kNW][2][5][kTC];        // column-pass state leaving wave r (slot = step parity)
+    __shared__ float mbD[kNW][2][5][4];
+    __shared__ float dummy[64 * 9];              // scratch column for lanes without column work
+
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row band of this wave
+    const bool isB = lane < kTC;
+    const bool isD = lane >= kTC && lane < kTC + 4;
+    const int jj = lane - kTC;
+
+    for (long long f = blockIdx.x; f < n; f += gridDim.x) {
+        const uint8_t* row_ptr = frames + (size_t)f * kF * kF * CH + (size_t)(r < 8 ? 64 * r + lane : 0) * kF * CH;
+        float* dst = out64 + (size_t)f * 4096;
+        float sA = 0.0f, lagA[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float sC = 0.0f, lagC[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        StripRaw<CH> raw;
+        if (r < 8) load_strip_raw<CH>(row_ptr, 0, raw);
+
+#pragma unroll 1
+        for (int t = 0; t <= 8 + 17; ++t) {
+            const int c = t - r;  // tile column of this wave in this step (wave-uniform)
+
+            // ---------------- A: rep-1 along the input row ------------------------------------
+            if (r < 8 && c >= 0 && c <= 16) {
+                float* xrow = &X[r][lane][0];
+                if (c < 16) {
+                    float v[kS];
+                    strip_luma<CH>(raw, v);
+                    if (c < 15) load_strip_raw<CH>(row_ptr, c + 1, raw);
+                    if (c == 0) {
+                        sA = __fadd_rn(sA, v[0]);
+                        sA = __fadd_rn(sA, v[1]);
+                        sA = __fadd_rn(sA, v[2]);
+                        xrow[2] = __fdiv_rn(sA, 3.0f);
+                        sA = __fadd_rn(sA, v[3]);
+                        xrow[3] = __fmul_rn(sA, 0.25f);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) lagA[k] = v[k];
+#pragma unroll
+                        for (int k = 4; k < kS; ++k) {
+                            sA = __fadd_rn(sA, v[k]);
+                            sA = __fsub_rn(sA, lagA[k & 3]);
+                            lagA[k & 3] = v[k];
+                            xrow[k] = __fmul_rn(sA, 0.25f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kS; ++k) {
+                            sA = __fadd_rn(sA, v[k]);
+                            sA = __fsub_rn(sA, lagA[k & 3]);
+                            lagA[k & 3] = v[k];
+                            xrow[k] = __fmul_rn(sA, 0.25f);
+                        }
+                    }
+                } else {  // steps 512, 513 (box1DFloat phase 4): labels 512 (/3) and 513 (/2)
+                    sA = __fsub_rn(sA, lagA[0]);
+                    xrow[0] = __fdiv_rn(sA, 3.0f);
+                    sA = __fsub_rn(sA, lagA[1]);
+                    xrow[1] = __fmul_rn(sA, 0.5f);
+                }
+            }
+            wave_lds_sync();
+
+            // ---------------- B on tile column c  ||  D on tile column c - 1 ---------------------
+            {
+                const int cd = c - 1;
+                const bool b_on = isB && c >= 0 && c <= 16 && (c > 0 || lane >= 2) && (c < 16 || lane < 2);
+                const int jd = 4 * cd - 1 + jj;
+                const bool d_on = isD && cd >= 0 && cd <= 16 && jd >= 0 && jd <= 63;
+                const int par_in = (t - 1) & 1, par_out = t & 1;
+                Run5 st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                if (r > 0) {
+                    if (b_on) {
+                        st.sum = mbB[r - 1][par_in][0][lane]; st.l0 = mbB[r - 1][par_in][1][lane];
+                        st.l1 = mbB[r - 1][par_in][2][lane]; st.l2 = mbB[r - 1][par_in][3][lane];
+                        st.l3 = mbB[r - 1][par_in][4][lane];
+                    } else if (d_on) {
+                        st.sum = mbD[r - 1][par_in][0][jj]; st.l0 = mbD[r - 1][par_in][1][jj];
+                        st.l1 = mbD[r - 1][par_in][2][jj]; st.l2 = mbD[r - 1][par_in][3][jj];
+                        st.l3 = mbD[r - 1][par_in][4][jj];
+                    }
+                }
+                float* p = &dummy[r * 64];
+                int stride = 0;
+                if (b_on) {
+                    p = &X[r][0][lane];
+                    stride = kTC + 1;
+                } else if (d_on) {
+                    p = &Z[r][cd & 1][jj][0];
+                    stride = 1;
+                }
+                if (r == 0) {
+                    // label rows 0..7: the filter's start-up (B starts at row 0, D at label row 2)
+                    const int first = d_on ? 2 : 0;
+                    float lg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float x = p[q * stride];
+                        const bool valid = q >= first;
+                        const bool sub = q >= first + 4;
+                        float s2 = __fadd_rn(st.sum, x);
+                        if (sub) s2 = __fsub_rn(s2, lg[q & 3]);
+                        st.sum = valid ? s2 : st.sum;
+                        lg[q & 3] = valid ? x : lg[q & 3];
+                        const float o = (q - first == 2) ? __fdiv_rn(st.sum, 3.0f) : __fmul_rn(st.sum, 0.25f);
+                        if (q - first >= 2) p[q * stride] = o;
+                    }
+                    st.l0 = lg[0]; st.l1 = lg[1]; st.l2 = lg[2]; st.l3 = lg[3];
+                    // label rows 8..63: steady state (same chunk macro as colpass64_steady)
+                    const bool emit = d_on;
+                    const int i0 = -1, j = jd;
+                    float a8[8], b8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a8[e] = p[(8 + e) * stride];
+#pragma unroll 1
+                    for (int q0 = 8; q0 < 56; q0 += 16) {  // chunk pairs (8,16) (24,32) (40,48)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b8[e] = p[(q0 + 8 + e) * stride];
+                        HVD_RUN_CHUNK(a8, q0)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a8[e] = p[(q0 + 16 + e) * stride];
+                        HVD_RUN_CHUNK(b8, q0 + 8)
+                    }
+                    HVD_RUN_CHUNK(a8, 56)  // a8 holds rows 56..63
+                } else if (r < 8) {
+                    colpass64_steady(p, stride, st, d_on, dst, 8 * r - 1, jd);
+                } else {
+                    // label rows 512, 513: B's phase 4 (subtract only: /3, /2); D's last sample (label 512)
+                    const float x0 = d_on ? p[0] : 0.0f;  // B lanes add nothing (sum + 0 is exact)
+                    st.sum = __fsub_rn(__fadd_rn(st.sum, x0), st.l0);
+                    if (b_on) p[0] = __fdiv_rn(st.sum, 3.0f);
+                    if (d_on) dst[63 * 64 + jd] = __fmul_rn(st.sum, 0.25f);
+                    if (b_on) {
+                        st.sum = __fsub_rn(st.sum, st.l1);
+                        p[stride] = __fmul_rn(st.sum, 0.5f);
+                    }
+                }
+                if (r < 8) {
+                    if (b_on) {
+                        mbB[r][par_out][0][lane] = st.sum; mbB[r][par_out][1][lane] = st.l0;
+                        mbB[r][par_out][2][lane] = st.l1; mbB[r][par_out][3][lane] = st.l2;
+                        mbB[r][par_out][4][lane] = st.l3;
+                    } else if (d_on) {
+                        mbD[r][par_out][0][jj] = st.sum; mbD[r][par_out][1][jj] = st.l0;
+                        mbD[r][par_out][2][jj] = st.l1; mbD[r][par_out][3][jj] = st.l2;
+                        mbD[r][par_out][4][jj] = st.l3;
+                    }
+                }
+            }
+            wave_lds_sync();
+
+            // ---------------- C: rep-2 along the label row -------------------------------------
+            // label column u = 32c + k is filter input index u - 2; ring slot (k + 2) & 3; the output is a
+            // decimation sample iff k is a multiple of 8 (u >= 8): sample column j = u/8 - 1, slot k/8
+            if (c >= 0 && c <= 16 && (r < 8 || lane < 2)) {
+                const float* xrow = &X[r][lane][0];
+                float* z = &Z[r][c & 1][0][lane];
+                if (c == 0) {
+                    const float t0 = xrow[2], t1 = xrow[3], t2 = xrow[4], t3 = xrow[5];
+                    sC = __fadd_rn(__fadd_rn(__fadd_rn(t0, t1), t2), t3);
+                    lagC[0] = t0; lagC[1] = t1; lagC[2] = t2; lagC[3] = t3;
+#pragma unroll
+                    for (int k = 6; k < kTC; ++k) {
+                        const float x = xrow[k];
+                        sC = __fsub_rn(__fadd_rn(sC, x), lagC[(k + 2) & 3]);
+                        lagC[(k + 2) & 3] = x;
+                        if ((k & 7) == 0) z[(k >> 3) * (kTR + 1)] = __fmul_rn(sC, 0.25f);
+                    }
+                } else if (c < 16) {
+#pragma unroll
+                    for (int k = 0; k < kTC; ++k) {
+                        const float x = xrow[k];
+                        sC = __fsub_rn(__fadd_rn(sC, x), lagC[(k + 2) & 3]);
+                        lagC[(k + 2) & 3] = x;
+                        if ((k & 7) == 0) z[(k >> 3) * (kTR + 1)] = __fmul_rn(sC, 0.25f);
+                    }
+                } else {
+                    const float x = xrow[0];  // label column 512: sample column 63
+                    sC = __fsub_rn(__fadd_rn(sC, x), lagC[2]);
+                    z[0] = __fmul_rn(sC, 0.25f);
+                }
+            }
+            __syncthreads();  // mailboxes of this step are complete; also orders Z for the next step's D
+        }
+    }
+}
+#undef HVD_RUN_CHUNK
+#undef HVD_RUN_STEP
+
 }  // namespace
 
 namespace hvd {
@@ -618,6 +879,7 @@ static int jarosz_window(int dim) { return (dim + 2 * 64 - 1) / (2 * 64); }
 // Workspace (floats per frame) the down-sampler needs besides the 64x64 output.
 size_t pdq_downsample_ws_floats(int h, int w) { return 2 * (size_t)h * w + (size_t)64 * h; }
 
+bool g_pdq_down512_systolic = false;  // A/B switch: k_down512s instead of k_down512
 bool g_pdq_fused_down512 = true;  // A/B switch (hvd_debug_set "pdq_fused_down512")
 
 hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int w, int channels, float* d_ws,
@@ -625,7 +887,13 @@ hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int 
     if (n <= 0) return hipSuccess;
     if (h == kF && w == kF && g_pdq_fused_down512) {
         const unsigned grid = (unsigned)(n < 512 ? n : 512);  // 2 workgroups per CU fit by LDS (75.8 KB each)
-        if (channels == 3)
+        if (g_pdq_down512_systolic) {
+            const unsigned gs = (unsigned)(n < 256 ? n : 256);  // one workgroup per CU (LDS)
+            if (channels == 3)
+                hipLaunchKernelGGL(k_down512s<3>, dim3(gs), dim3(kNW * 64), 0, s, d_frames, (long long)n, d_out64);
+            else
+                hipLaunchKernelGGL(k_down512s<1>, dim3(gs), dim3(kNW * 64), 0, s, d_frames, (long long)n, d_out64);
+        } else if (channels == 3)
             hipLaunchKernelGGL(k_down512<3>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
         else
             hipLaunchKernelGGL(k_down512<1>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);

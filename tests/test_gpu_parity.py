@@ -468,3 +468,23 @@ def test_k2_full_size_10m_sharded_8_ways(gpu, hvd):
     assert want <= found and len(found) - len(want) <= len(want) // 10 + 5
     sizes = [len(p) for p in parts]
     assert min(sizes) > 0.5 * max(sizes), sizes  # planted pairs are uniform over the triangle
+
+
+def test_k1_down512_all_three_forms_agree(gpu, hvd, oracle):
+    """512x512 front-end: generic 4-launch path, fused strip kernel (default) and the systolic
+    kernel are interchangeable bit for bit (rgb24 and gray)."""
+    lib = gpu.load()
+    rgb = hvd.synth.frames_rgb(5, seed=91)
+    gray = hvd.synth.frames_gray(5, seed=92, h=512, w=512)
+    want_rgb = oracle.hash_frames(rgb, num_threads=8)
+    want_gray = oracle.hash_frames(gray, num_threads=8)
+    try:
+        for fused, systolic in ((0, 0), (1, 0), (1, 1)):
+            gpu.check(lib.hvd_debug_set(b"pdq_fused_down512", fused))
+            gpu.check(lib.hvd_debug_set(b"pdq_down512_systolic", systolic))
+            for fr, (ho, qo) in ((rgb, want_rgb), (gray, want_gray)):
+                h, q = hvd.vpdq.hash_frames(fr)
+                assert np.array_equal(h, ho) and np.array_equal(q, qo), (fused, systolic, fr.shape)
+    finally:
+        gpu.check(lib.hvd_debug_set(b"pdq_fused_down512", 1))
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_systolic", 0))
