@@ -162,6 +162,30 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_cmp / (elapsed / args.steps)
 
+    # ---------------- frames hashed / s (BASELINE configs[1]), every rank hashes its own batch ----
+    fr = synth.frames_gray(args.frames, seed=2)
+    d_f = L.DeviceBuffer.from_array(fr)
+    d_h = L.DeviceBuffer(32 * args.frames)
+    d_q = L.DeviceBuffer(4 * args.frames)
+    reps = 20
+    L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, args.frames, 64, 64, 1, None, d_h.ptr, d_q.ptr))
+    barrier()
+    t0 = time.perf_counter()
+    L.check(lib.hvd_timer_start())
+    for _ in range(reps):
+        L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, args.frames, 64, 64, 1, None, d_h.ptr, d_q.ptr))
+    ms = C.c_float(0)
+    L.check(lib.hvd_timer_stop(C.byref(ms)))
+    barrier()
+    k1_wall = time.perf_counter() - t0
+    k1_ms = ms.value / reps
+    if dist is not None:
+        import torch
+
+        tw = torch.tensor([k1_wall, k1_ms], dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        k1_wall, k1_ms = float(tw[0].item()), float(tw[1].item())
+
     if rank != 0:
         if exchange is not None:
             exchange.close()
@@ -218,33 +242,20 @@ def main():
             extra[name] = {"kernel_ms": round(float(np.mean(ks)), 3),
                            "comparisons_per_s": float(f"{total_cmp / (np.mean(ks) * 1e-3):.4g}")}
 
-    # ---------------- frames hashed / s (BASELINE configs[1]) --------------------------
-    frames_out = None
+    fps = world * args.frames / (k1_ms * 1e-3)
+    frames_out = {
+        "workload": f"{args.frames} pre-decoded synthetic 64x64 gray frames per GPU -> PDQ hash + quality "
+                    "(BASELINE configs[1]; frames are independent, ranks hash disjoint batches, no collective)",
+        "value": float(f"{fps:.4g}"), "unit": "frames/s", "kernel_ms": round(k1_ms, 4), "dtype": "f32",
+        "n_gpus": world, "wall_value": float(f"{world * args.frames * reps / k1_wall:.4g}"),
+        "roofline": {"bound": "hbm", "kernel": "k_pdq_hash64", "achieved": round(fps / world * BYTES_PER_FRAME_64 / 1e9, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(fps / world * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "note": "fp32-VALU-bound at 64x64 (bit-exact non-FMA DCT: 2 VALU ops per MAC; PMC: SIMDs "
+                             "issue-saturated, profiles/r01_pmc_k1.txt), not HBM-bound"},
+    }
     cpu = None
     if world == 1:
-        fr = synth.frames_gray(args.frames, seed=2)
-        d_f = L.DeviceBuffer.from_array(fr)
-        d_h = L.DeviceBuffer(32 * args.frames)
-        d_q = L.DeviceBuffer(4 * args.frames)
-        reps = 20
-        L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, args.frames, 64, 64, 1, None, d_h.ptr, d_q.ptr))
-        L.check(lib.hvd_dev_sync())
-        L.check(lib.hvd_timer_start())
-        for _ in range(reps):
-            L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, args.frames, 64, 64, 1, None, d_h.ptr, d_q.ptr))
-        ms = C.c_float(0)
-        L.check(lib.hvd_timer_stop(C.byref(ms)))
-        k1_ms = ms.value / reps
-        fps = args.frames / (k1_ms * 1e-3)
-        frames_out = {
-            "workload": f"{args.frames} pre-decoded synthetic 64x64 gray frames -> PDQ hash + quality "
-                        "(BASELINE configs[1])",
-            "value": float(f"{fps:.4g}"), "unit": "frames/s", "kernel_ms": round(k1_ms, 4), "dtype": "f32",
-            "roofline": {"bound": "hbm", "kernel": "k_pdq_hash64", "achieved": round(fps * BYTES_PER_FRAME_64 / 1e9, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(fps * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "note": "fp32-VALU-bound at 64x64 (bit-exact non-FMA DCT: 2 VALU ops per MAC), not HBM-bound"},
-        }
         # the reference's real frame geometry: 512x512 packed RGB24 (vpdqpy/vpdqpy.py:90-95)
         n_rgb = 1024
         rgb = synth.frames_rgb(16, seed=6)

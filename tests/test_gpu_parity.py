@@ -257,6 +257,11 @@ def test_k2_rccl_exchange_single_rank(gpu, hvd):
         got = hvd.multigpu.merge_pairs([ex.allgather_pairs_dev(d_pairs.ptr, cnt)])
         assert np.array_equal(got, hvd.allpairs_hamming(db, 31))
         assert len(ex.allgather_pairs_dev(d_pairs.ptr, 0)) == 0
+        # all-gather of hash shards produced on-device (config 5: hash on every GPU, replicate the DB)
+        d_out = gpu.DeviceBuffer(32 * n)
+        gpu.check(gpu.load().hvd_comm_allgather_bytes(d_db.ptr, d_out.ptr, 32 * n))
+        gpu.check(gpu.load().hvd_dev_sync())
+        assert np.array_equal(d_out.to_array(np.uint8, 32 * n).reshape(-1, 32), db)
     finally:
         ex.close()
 
