@@ -49,6 +49,11 @@ def parse():
 
 
 def main():
+    # Native libraries (gloo, RCCL) print banners on fd 1; the contract is ONE JSON line on stdout.
+    # Keep the real stdout aside and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -338,7 +343,8 @@ def main():
         out["frames_hashed"] = frames_out
     if cpu:
         out["cpu_baseline"] = cpu
-    print(json.dumps(out))
+    real_stdout.write(json.dumps(out) + "\n")
+    real_stdout.flush()
     if exchange is not None:
         exchange.close()
     if dist is not None:
