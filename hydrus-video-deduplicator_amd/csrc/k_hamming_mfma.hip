@@ -94,7 +94,7 @@ __device__ __forceinline__ void append_pair_m(hvd_pair* out, unsigned long long 
     }
 }
 
-constexpr int kSuper = 128;  // candidates per LDS super-panel
+constexpr int kSuper = 128;  // candidates per LDS super-panel (256: -4 % with the prefilter, +2 % without)
 
 __device__ __forceinline__ v4i as_v4i(const uint4& v) { return v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
 
@@ -152,7 +152,7 @@ __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, cons
 __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src, uint4* lds_dst, uint32_t wave,
                                                   uint32_t lane) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kSuper * 8 / 256; ++q) {
         const uint32_t chunk0 = (uint32_t)q * 256u + wave * 64u;  // first 16-B chunk of this wave-instruction
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + chunk0 + lane),
