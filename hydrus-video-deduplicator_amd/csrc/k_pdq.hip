@@ -46,20 +46,22 @@ __device__ __forceinline__ float luma_gray(uint32_t g) {
 }
 
 // |(int)(((u - v) * 100) / 255)| (pdqhashing.cpp quality metric) as a non-negative integer-valued
-// float, WITHOUT the IEEE division (10+ VALU ops): q = |x| * (1/255) is within one of the true
-// quotient's integer part; the remainder r = |x| - 255*trunc(q) is exact in one fma (|x| and
-// 255*m are both multiples of ulp(|x|) and close), and r < 0 / r >= 255 says which way to fix it.
-// Equality with (int)(x / 255.0f) is checked for EVERY float |x| <= 26000 by
-// tests/tools/check_div255.c (2.4e9 values, 0 mismatches); |x| <= 25500.01 here because luma and
-// its box-filter averages never exceed 255.0001. The fma is this kernel's own exact-arithmetic
-// device, not a contraction of reference arithmetic.
-__device__ __forceinline__ float grad_term(float u, float v) {
+// float, WITHOUT the IEEE division (10+ VALU ops). The multiplier is the float just BELOW 1/255
+// (RN(1/255) = 0x1.010102p-8 lies above the true value), so q = |x| * c stays below the true
+// quotient even after its own rounding: trunc(q) is floor(|x|/255) or one less. The remainder
+// r = |x| - 255*m is exact in one fma (|x| and 255*m are multiples of ulp(|x|) and close) and
+// r >= 255 says when to add one. Equality with (int)(x / 255.0f) is checked for EVERY float
+// |x| <= 26000 by tests/tools/check_div255.c (2.4e9 values, 0 mismatches); |x| <= 25500.01 here
+// because luma and its box-filter averages never exceed 255.0001. The fma is this kernel's own
+// exact-arithmetic device, not a contraction of reference arithmetic.
+// The term is m + (r >= 255): the caller accumulates the m's as floats (exact: integers far below
+// 2^24) and the corrections as an integer count (v_cmp + add-with-carry).
+__device__ __forceinline__ void grad_term(float u, float v, float& acc_m, int& acc_c) {
     const float ax = fabsf(__fmul_rn(__fsub_rn(u, v), 100.0f));
-    float m = truncf(__fmul_rn(ax, 1.0f / 255.0f));
+    const float m = truncf(__fmul_rn(ax, 0x1.0101p-8f));
     const float r = __fmaf_rn(-255.0f, m, ax);
-    m = r < 0.0f ? m - 1.0f : m;
-    m = r >= 255.0f ? m + 1.0f : m;
-    return m;
+    acc_m += m;
+    acc_c += (r >= 255.0f) ? 1 : 0;
 }
 
 __device__ __forceinline__ float wave_sum_f32(float v) {  // exact: integer-valued, far below 2^24
@@ -110,18 +112,17 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             }
 
             // ---- quality -----------------------------------------------------------
-            float gs = 0.0f;
+            float gs = 0.0f, gh = 0.0f;
+            int cs_ = 0, ch_ = 0;
 #pragma unroll
-            for (int k = 0; k < 63; ++k) gs += grad_term(a[k], a[k + 1]);
+            for (int k = 0; k < 63; ++k) grad_term(a[k], a[k + 1], gs, cs_);
 #pragma unroll
-            for (int k = 0; k < 64; ++k) {
-                const float right = __shfl_down(a[k], 1, 64);
-                const float t = grad_term(a[k], right);
-                gs += (lane < 63) ? t : 0.0f;
-                // keep the scheduler from hoisting all 64 cross-lane reads (64 extra live VGPRs)
-                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < 64; ++k) grad_term(a[k], __shfl_down(a[k], 1, 64), gh, ch_);
+            if (lane < 63) {  // column 63 has no right neighbour
+                gs += gh;
+                cs_ += ch_;
             }
-            const int gsum = (int)wave_sum_f32(gs);
+            const int gsum = (int)wave_sum_f32(gs + (float)cs_);
             int qual = gsum / 90;
             qual = qual > 100 ? 100 : qual;
 
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
                 key[r] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving
             }
             uint32_t prefix = 0, mask = 0;
-            int kth = 128;
+            int kth = 128, remaining = 256;
 #pragma unroll 1
             for (int bit = 31; bit >= 0; --bit) {
                 const uint32_t bsel = 1u << bit;
@@ -203,9 +204,20 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
                 for (int r = 0; r < 4; ++r) cnt0 += __popcll(__ballot((key[r] & m2) == prefix));
                 if (kth > cnt0) {
                     kth -= cnt0;
+                    remaining -= cnt0;
                     prefix |= bsel;
+                } else {
+                    remaining = cnt0;
                 }
                 mask = m2;
+                if (remaining == 1) break;  // a single key carries this prefix: it is the median
+            }
+            if (mask != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned long long bm = __ballot((key[r] & mask) == prefix);
+                    if (bm) prefix = __builtin_amdgcn_readlane(key[r], (int)__builtin_ctzll(bm));
+                }
             }
             const uint32_t mu = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
             const float med = __uint_as_float(mu);

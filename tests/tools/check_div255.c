@@ -6,12 +6,14 @@
 #include <stdlib.h>
 #include <string.h>
 static inline int fast_form(float x) {
+    /* multiplier = the float just BELOW 1/255 (RN(1/255) = 0x1.010102p-8 lies above it): the product,
+     * even after its own rounding, stays below the true quotient, so trunc() is never too large and a
+     * single "remainder >= 255" correction suffices. */
+    const float c = 0x1.0101p-8f;
     float ax = fabsf(x);
-    float q = ax * (1.0f / 255.0f);       // approximate quotient (one rounding of the constant, one of the product)
-    float m = truncf(q);                   // candidate, within 1 of floor(ax/255)
-    float r = fmaf(-255.0f, m, ax);        // exact remainder ax - 255*m
-    if (r < 0.0f) m -= 1.0f;               // candidate one too large
-    else if (r >= 255.0f) m += 1.0f;       // candidate one too small
+    float m = truncf(ax * c);            /* candidate: floor(ax/255) or one less */
+    float r = fmaf(-255.0f, m, ax);      /* exact remainder ax - 255*m */
+    if (r >= 255.0f) m += 1.0f;
     int d = (int)m;
     return x < 0 ? -d : d;
 }
