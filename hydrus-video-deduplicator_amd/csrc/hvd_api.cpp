@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "hvd_kernels.h"
@@ -57,6 +58,13 @@ struct Ctx {
     void* x_send = nullptr;
     void* x_recv = nullptr;
     size_t x_send_cap = 0, x_recv_cap = 0;
+    // grow-only scratch of the legacy one-pair entry (hvd_match_two): a, b, flags, result
+    void* m_a = nullptr;
+    void* m_b = nullptr;
+    void* m_f = nullptr;
+    void* m_o = nullptr;
+    size_t m_a_cap = 0, m_b_cap = 0, m_f_cap = 0;
+    std::mutex m_mu;
 };
 Ctx g;
 std::mutex g_mu;
@@ -91,6 +99,7 @@ bool pair_less(const hvd_pair& x, const hvd_pair& y) { return x.i != y.i ? x.i <
 }  // namespace
 
 static void free_exchange_buffers();
+static int grow(void** p, size_t* cap, size_t need);
 
 namespace hvd {
 int api_fail(int code, const char* fmt, ...) {
@@ -173,7 +182,10 @@ int hvd_shutdown(void) {
     (void)hipEventDestroy(g.ev0);
     (void)hipEventDestroy(g.ev1);
     (void)hipStreamDestroy(g.stream);
-    g = Ctx();
+    for (void** p : {&g.m_a, &g.m_b, &g.m_f, &g.m_o})
+        if (*p) (void)hipFree(*p);
+    g.~Ctx();
+    new (&g) Ctx();
     return HVD_OK;
 }
 
@@ -564,17 +576,18 @@ int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, in
     *t_hits = 0;
     if (na == 0 || nb == 0) return HVD_OK;  // either side empty => no match (db/DedupeDB.py:555-557)
     if (!a || !b) return fail(HVD_ERR_ARG, "NULL hash buffer");
-    DevBuf d_a, d_b, d_f, d_o;
-    HIP_TRY(d_a.alloc(32 * (size_t)na));
-    HIP_TRY(d_b.alloc(32 * (size_t)nb));
-    HIP_TRY(d_f.alloc(4 * (size_t)nb));
-    HIP_TRY(d_o.alloc(8));
-    HIP_TRY(hipMemcpyAsync(d_a.p, a, 32 * (size_t)na, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(d_b.p, b, 32 * (size_t)nb, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hvd::launch_match_two(d_a.as<uint32_t>(), (uint32_t)na, d_b.as<uint32_t>(), (uint32_t)nb,
-                                  (uint32_t)max_dist, d_f.as<uint32_t>(), d_o.as<int32_t>(), g.stream));
+    // The VP-tree issues one such call per visited node (db/vptree.py:737): no malloc/free per call.
+    std::lock_guard<std::mutex> lk(g.m_mu);
+    if (int rc = grow(&g.m_a, &g.m_a_cap, 32 * (size_t)na)) return rc;
+    if (int rc = grow(&g.m_b, &g.m_b_cap, 32 * (size_t)nb)) return rc;
+    if (int rc = grow(&g.m_f, &g.m_f_cap, 4 * (size_t)nb)) return rc;
+    if (!g.m_o) HIP_TRY(hipMalloc(&g.m_o, 8));
+    HIP_TRY(hipMemcpyAsync(g.m_a, a, 32 * (size_t)na, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.m_b, b, 32 * (size_t)nb, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hvd::launch_match_two((const uint32_t*)g.m_a, (uint32_t)na, (const uint32_t*)g.m_b, (uint32_t)nb,
+                                  (uint32_t)max_dist, (uint32_t*)g.m_f, (int32_t*)g.m_o, g.stream));
     int32_t hits[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(hits, d_o.p, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(hits, g.m_o, 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     *q_hits = hits[0];
     *t_hits = hits[1];
