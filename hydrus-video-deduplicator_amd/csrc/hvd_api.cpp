@@ -91,6 +91,10 @@ struct DevBuf {
 
 int need_ready() {
     if (!g.ready) return fail(HVD_ERR_STATE, "hvd_init() has not been called (no CPU fallback exists)");
+    // HIP's current device is per host thread; the reference calls this path from the main thread or
+    // from a QThread worker (gui/gui.py:195-237), so every entry re-asserts the bound device.
+    hipError_t e = hipSetDevice(g.device);
+    if (e != hipSuccess) return fail(HVD_ERR_HIP, "hipSetDevice(%d): %s", g.device, hipGetErrorString(e));
     return HVD_OK;
 }
 
@@ -109,7 +113,11 @@ int api_fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
-const float* api_dct_device() { return g.ready ? g.d_dct : nullptr; }
+const float* api_dct_device() {
+    if (!g.ready) return nullptr;
+    (void)hipSetDevice(g.device);
+    return g.d_dct;
+}
 }  // namespace hvd
 
 extern "C" {

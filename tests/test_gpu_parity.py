@@ -550,3 +550,34 @@ def test_randomized_differential_sweep(gpu, hvd, oracle, seed):
     hh, qq = hvd.vpdq.hash_frames(fr)
     ho, qo = oracle.hash_frames(fr, num_threads=4)
     assert np.array_equal(hh, ho) and np.array_equal(qq, qo), (h, w, fr.shape)
+
+
+def test_entry_points_from_a_worker_thread(gpu, hvd, oracle):
+    """The reference drives this path from a QThread worker (gui/gui.py:195-237): hashing, matching
+    and searching must work from a thread other than the one that called hvd_init."""
+    import threading
+
+    fr = hvd.synth.frames_gray(64, seed=93)
+    db, _ = hvd.synth.hash_db(3000, seed=94, plant_fraction=0.02)
+    out = {}
+
+    def work():
+        try:
+            out["h"] = hvd.vpdq.hash_frames(fr)
+            out["p"] = hvd.allpairs_hamming(db, 31)
+            hs = hvd.VideoHasher(1, 64, 64, 0)
+            for f in fr:
+                hs.hash_frame(f)
+            out["v"] = hs.finish()
+            out["m"] = hvd.matchHashBytes(db[:10].tobytes(), db[:10].tobytes(), 31)
+        except Exception as exc:  # surfaced below
+            out["err"] = exc
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert "err" not in out, out.get("err")
+    ho, qo = oracle.hash_frames(fr)
+    assert np.array_equal(out["h"][0], ho) and np.array_equal(out["h"][1], qo)
+    assert np.array_equal(out["p"], oracle.allpairs(db, 31))
+    assert out["v"].bytes == ho[qo >= 31].tobytes() and out["m"] == 100.0
