@@ -79,6 +79,7 @@ def main():
     dist = None
     exchange = None
     exchange_kind = "none"
+    hard_exit = False  # a bootstrap thread stuck inside RCCL cannot be joined: leave with os._exit
     if world > 1:
         import torch.distributed as dist_mod
 
@@ -87,13 +88,35 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         boot = M.TorchDistExchange()
         uid = boot.broadcast_bytes(M.RcclExchange.create_unique_id() if rank == 0 else None, 128, src=0)
-        try:
-            exchange = M.RcclExchange(rank, world, uid)
+        # ncclCommInitRank is collective; bound it so that a hung bootstrap degrades to the gloo exchange
+        # (reported in the JSON) instead of producing no measurement at all.
+        import threading
+
+        box = {}
+
+        def _init():
+            try:
+                box["ex"] = M.RcclExchange(rank, world, uid)
+            except Exception as exc:
+                box["err"] = exc
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("HVD_RCCL_INIT_TIMEOUT", "120")))
+        ok = 1 if ("ex" in box and not th.is_alive()) else 0
+        import torch
+
+        agree = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)  # all ranks use RCCL, or none does
+        if int(agree.item()) == 1:
+            exchange = box["ex"]
             exchange_kind = "rccl"
-        except Exception as exc:  # reported in the JSON line, never silent
-            print(f"[bench] rank {rank}: RCCL init failed ({exc}); exchanging candidates over gloo", file=sys.stderr)
+        else:
+            why = "timed out" if th.is_alive() else repr(box.get("err", "failed on another rank"))
+            print(f"[bench] rank {rank}: RCCL init {why}; exchanging candidates over gloo", file=sys.stderr)
             exchange = None
             exchange_kind = "gloo-fallback"
+            hard_exit = th.is_alive()
 
     def barrier():
         L.check(lib.hvd_dev_sync())
@@ -197,6 +220,8 @@ def main():
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+        if hard_exit:
+            os._exit(0)
         return
 
     # kernel-level roofline (rank 0's share of the comparisons per launch)
@@ -350,6 +375,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if hard_exit:
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -9,10 +9,10 @@ from oracle import oracle as O
 lib = L.init(0)
 fr = synth.frames_gray(10000, seed=2)
 ho, qo = O.hash_frames(fr, num_threads=32)
-for dl in (0, 1, 2):
-    L.check(lib.hvd_debug_set(b"pdq_luma_lut", dl))
+for dl in (0, 1):
+    L.check(lib.hvd_debug_set(b"pdq_dct_from_lds", dl))
     h, q = hvd_amd.vpdq.hash_frames(fr)
-    print(f"luma_lut={dl}: hash mismatches {int((h != ho).any(1).sum())} quality mismatches {int((q != qo).sum())}")
+    print(f"dct_from_lds={dl}: hash mismatches {int((h != ho).any(1).sum())} quality mismatches {int((q != qo).sum())}")
     for n in (10_000, 400_000):
         f = np.concatenate([fr] * (n // len(fr)))
         d_f = L.DeviceBuffer.from_array(f); d_h = L.DeviceBuffer(32 * n); d_q = L.DeviceBuffer(4 * n)
