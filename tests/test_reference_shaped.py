@@ -15,11 +15,28 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def source_clip(rng, frames, h=128, w=128):
+    """A high-contrast scene that drifts slowly over time (what a real clip looks like to PDQ)."""
+    yy, xx = np.meshgrid(np.arange(h) / h, np.arange(w) / w, indexing="ij")
+    comps = [(rng.uniform(0.5, 4), rng.uniform(0.5, 4), rng.uniform(0, 6.28), rng.uniform(15, 45), rng.uniform(-0.05, 0.05))
+             for _ in range(8)]
+    out = np.empty((frames, h, w, 3), np.uint8)
+    for t in range(frames):
+        img = np.full((h, w), 128.0)
+        for fx, fy, ph, amp, drift in comps:
+            img += amp * np.cos(2 * np.pi * (fx * xx + fy * yy) + ph + drift * t * 6.28)
+        g = np.clip(img, 0, 255)
+        out[t, ..., 0] = g
+        out[t, ..., 1] = np.clip(g * 0.9 + 10, 0, 255)
+        out[t, ..., 2] = np.clip(255 - g * 0.8, 0, 255)
+    return out
+
+
 def make_clips(hvd, n_groups=6, frames=24, seed=500):
     rng = np.random.default_rng(seed)
     clips = {}
     for g in range(n_groups):
-        src = hvd.synth.frames_rgb(frames, seed=seed + 10 * g, h=128, w=128)
+        src = source_clip(rng, frames)
         clips[f"S{g:02d}_original"] = src
         noisy = np.clip(src.astype(np.int16) + rng.integers(-3, 4, src.shape), 0, 255).astype(np.uint8)
         clips[f"S{g:02d}_reencode"] = noisy
