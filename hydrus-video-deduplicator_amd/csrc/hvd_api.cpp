@@ -263,6 +263,11 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_pdq_luma_lut = value;
         return HVD_OK;
     }
+    if (strcmp(key, "fp4_code") == 0) {
+        if (value != 1 && value != 2 && value != 4 && value != 6) return fail(HVD_ERR_ARG, "fp4_code must be 1, 2, 4 or 6");
+        hvd::g_fp4_code = (uint32_t)value;
+        return HVD_OK;
+    }
     if (strcmp(key, "mfma_col_chunk_max") == 0) {
         if (value < 256 || value % 128) return fail(HVD_ERR_ARG, "mfma_col_chunk_max must be a multiple of 128, >= 256");
         hvd::g_mfma_col_chunk_max = (uint32_t)value;

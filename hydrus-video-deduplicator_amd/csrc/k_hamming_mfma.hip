@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t img_slot(uint32_t hash, uint32_t chunk) { re
 
 // One thread per (hash, chunk). Rows >= n (padding up to n_pad) become FP4 zeros.
 __global__ __launch_bounds__(256) void k_expand_fp4(const uint32_t* __restrict__ db, uint32_t n, uint32_t n_pad,
-                                                    uint4* __restrict__ img) {
+                                                    uint4* __restrict__ img, uint32_t code) {
     const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (idx >= (uint64_t)n_pad * 8u) return;
     const uint32_t hash = (uint32_t)(idx >> 3), chunk = (uint32_t)(idx & 7u);
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_expand_fp4(const uint32_t* __restrict__
         const uint32_t w = db[(size_t)hash * 8u + chunk];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            uint32_t x = 0x22222222u;  // +1.0 in every nibble
+            uint32_t x = 0x11111111u * code;  // +v in every nibble (code 2 = +1.0)
 #pragma unroll
             for (int t = 0; t < 8; ++t) x |= ((w >> (8 * d + t)) & 1u) << (4 * t + 3);  // bit set -> sign -> -1.0
             o[d] = x;
@@ -121,7 +121,7 @@ __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, cons
                                              const int32_t* __restrict__ group, float thr_full,
                                              hvd_pair* __restrict__ out, unsigned long long cap,
                                              unsigned long long* __restrict__ count, bool rect, uint32_t nq,
-                                             const int32_t* __restrict__ group_t) {
+                                             const int32_t* __restrict__ group_t, float inv_scale2) {
     v4i bf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) bf[s] = as_v4i(base[(2u * s + h) ^ sw]);
@@ -138,7 +138,7 @@ __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, cons
             const uint32_t i = wrow0 + 32u * t + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h;
             if (acc[r] >= thr_full && j < n && (rect ? i < nq : i < j)) {
                 if (group == nullptr || group[i] != (rect ? group_t[j] : group[j]))
-                    append_pair_m(out, cap, count, i, j, (uint32_t)(256 - (int)acc[r]) >> 1);
+                    append_pair_m(out, cap, count, i, j, (uint32_t)(256 - (int)(acc[r] * inv_scale2)) >> 1);
             }
         }
     }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
                                                           hvd_pair* __restrict__ out, unsigned long long cap,
                                                           unsigned long long* __restrict__ count,
                                                           const uint4* __restrict__ img_q, uint32_t nq,
-                                                          const int32_t* __restrict__ group_t) {
+                                                          const int32_t* __restrict__ group_t, float scale2) {
     constexpr uint32_t WROWS = 32u * TILES, ROWS = 4u * WROWS;
     constexpr int NB = PREFILTER ? 2 : 4;
     __shared__ uint4 lds[2][kSuper * 8];
@@ -196,8 +196,9 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
         for (int s = 0; s < NB; ++s) a[t][s] = as_v4i(imgq[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
     }
 
-    const float thr_full = 256.0f - 2.0f * (float)max_dist;                       // > 0 (host guarantees)
-    const float thr_fast = PREFILTER ? 128.0f - 2.0f * (float)max_dist : thr_full;  // may be <= 0: then every
+    // every product is +-v*v = +-scale2, so all dot products (and thresholds) scale by scale2
+    const float thr_full = scale2 * (256.0f - 2.0f * (float)max_dist);                       // > 0 (host guarantees)
+    const float thr_fast = PREFILTER ? scale2 * (128.0f - 2.0f * (float)max_dist) : thr_full;  // may be <= 0: then every
     const int thr_bits = thr_fast > 0.0f ? __float_as_int(thr_fast) : (int)0x80000000;  // panel takes the slow path
 
     // candidates <= row0 cannot pair with rows >= row0 (i<j): start at the super-panel holding row0+1
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
 
             if (__builtin_expect(__any(mm >= thr_bits), 0))
                 panel_slow_path<TILES>(imgq, base, sw, wrow0, jsp + cl, n, h, li, group, thr_full, out, cap, count,
-                                       RECT, nq, group_t);
+                                       RECT, nq, group_t, 1.0f / scale2);
         }
 
         __syncthreads();  // (hipcc drains the in-flight global->LDS loads with vmcnt(0) first)
@@ -250,11 +251,19 @@ static uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 
 uint32_t fp4_rows_padded(uint32_t n) { return round_up(n ? n : 1, 1024u); }
 
+// e2m1 code of the magnitude used for the +-v image: 1 = 0.5, 2 = 1.0 (default), 4 = 2.0, 6 = 4.0.
+// Any of them is exact; the choice only changes what toggles in the multiplier array (power -> clock).
+uint32_t g_fp4_code = 2;
+static float fp4_scale2() {
+    const float v = g_fp4_code == 1 ? 0.5f : g_fp4_code == 2 ? 1.0f : g_fp4_code == 4 ? 2.0f : 4.0f;
+    return v * v;
+}
+
 hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s) {
     const uint32_t n_pad = fp4_rows_padded(n);
     const uint64_t threads = (uint64_t)n_pad * 8u;
     hipLaunchKernelGGL(k_expand_fp4, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_db, n,
-                       n_pad, (uint4*)d_img);
+                       n_pad, (uint4*)d_img, g_fp4_code);
     return hipGetLastError();
 }
 
@@ -296,7 +305,7 @@ static hipError_t launch_mfma_t(const AllPairsArgs& a, const void* d_img, hipStr
     dim3 grid((a.n + ROWS - 1) / ROWS, (n_pad + chunk - 1) / chunk);
     hipLaunchKernelGGL((k_allpairs_mfma<T, PF, false>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
                        a.d_group, a.max_dist, chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count,
-                       (const uint4*)nullptr, 0u, (const int32_t*)nullptr);
+                       (const uint4*)nullptr, 0u, (const int32_t*)nullptr, fp4_scale2());
     return hipGetLastError();
 }
 
@@ -317,7 +326,7 @@ static hipError_t launch_cross_t(const AllPairsArgs& a, const void* d_img_q, uin
     dim3 grid((unsigned)n_rb, (unsigned)((n_pad + chunk - 1) / chunk));
     hipLaunchKernelGGL((k_allpairs_mfma<T, PF, true>), grid, dim3(256), 0, s, (const uint4*)d_img_t, a.n, n_pad,
                        a.d_group, a.max_dist, (uint32_t)chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count,
-                       (const uint4*)d_img_q, nq, d_group_t);
+                       (const uint4*)d_img_q, nq, d_group_t, fp4_scale2());
     return hipGetLastError();
 }
 

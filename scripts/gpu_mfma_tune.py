@@ -8,10 +8,15 @@ from hvd_amd import _lib as L, synth, multigpu as M
 lib = L.init(0)
 n = 1_000_000
 db, _ = synth.hash_db(n, seed=3)
-d_db = L.DeviceBuffer.from_array(db); d_img = M.expand_fp4(d_db.ptr, n)
+d_db = L.DeviceBuffer.from_array(db)
 d_pairs = L.DeviceBuffer(16 << 20); d_cnt = L.DeviceBuffer(8)
-for chunk in (2048, 4096, 8192, 16384, 32768, 65536):
-    L.check(lib.hvd_debug_set(b"mfma_col_chunk_max", chunk))
+from oracle import oracle as O
+small, _ = synth.hash_db(3000, seed=9, plant_fraction=0.05)
+want = O.allpairs(small, 31)
+for chunk in (1, 2, 4, 6, 2):
+    L.check(lib.hvd_debug_set(b"fp4_code", chunk))
+    print("fp4_code", chunk, "parity:", np.array_equal(hvd_amd.allpairs_hamming(small, 31), want))
+    d_img = M.expand_fp4(d_db.ptr, n)
     for v in (9, 8):
         best = 1e9
         for r in range(4):
