@@ -327,6 +327,10 @@ def main():
             O.allpairs_count(db[:ns], 31, num_threads=cores)
             dt = time.perf_counter() - t
             cpu_cmp = ns * (ns - 1) / 2 / dt
+            n1 = min(n, 60_000)  # single-thread figure on a small prefix (~1-2 s)
+            t = time.perf_counter()
+            O.allpairs_count(db[:n1], 31, num_threads=1)
+            cpu_cmp_1t = n1 * (n1 - 1) / 2 / (time.perf_counter() - t)
             t = time.perf_counter()
             ho, qo = O.hash_frames(fr, num_threads=cores)
             dtf = time.perf_counter() - t
@@ -343,6 +347,7 @@ def main():
             cpu = {"value": float(f"{cpu_cmp:.4g}"), "unit": "comparisons/s", "cores": cores, "kind": "port",
                    "sample": f"oracle (C, popcnt, pthreads) all-pairs over the first {ns} of the {n} hashes "
                              f"({ns * (ns - 1) // 2:.3g} comparisons, {dt:.1f} s)",
+                   "value_1thread": float(f"{cpu_cmp_1t:.4g}"),
                    "frames_per_s": float(f"{args.frames / dtf:.4g}"),
                    "frames_sample": f"oracle PDQ over the same {args.frames} frames, {cores} threads, {dtf:.2f} s",
                    "note": "the reference's real CPU path (hvdaccelerators 0.4.0) is not installable offline; this "
