@@ -273,6 +273,14 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_mfma_col_chunk_max = (uint32_t)value;
         return HVD_OK;
     }
+    if (strcmp(key, "pdq_down512_strip64") == 0) {
+        hvd::g_pdq_down512_strip64 = value != 0;
+        return HVD_OK;
+    }
+    if (strcmp(key, "pdq_down512_split_d") == 0) {
+        hvd::g_pdq_down512_split_d = value != 0;
+        return HVD_OK;
+    }
     if (strcmp(key, "pdq_down512_systolic") == 0) {
         hvd::g_pdq_down512_systolic = value != 0;
         return HVD_OK;

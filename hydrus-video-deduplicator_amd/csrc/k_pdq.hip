@@ -364,32 +364,31 @@ __global__ __launch_bounds__(64) void k_box_scan_T(const void* __restrict__ in, 
 // order, so the result is bit-identical to the 4-launch generic path and to the oracle.
 constexpr int kF = 512;        // frame side
 constexpr int kS = 32;         // strip width
-constexpr int kBufLd = kS + 1; // odd row stride: lane=row accesses are bank-conflict free
 constexpr int kCsLd = kF + 1;
 
-template <int CH>
+template <int CH, int S = kS>
 struct StripRaw {
-    uint4 q[CH == 3 ? 6 : 2];
+    uint4 q[S * CH / 16];
 };
 
-template <int CH>
-__device__ __forceinline__ void load_strip_raw(const uint8_t* __restrict__ row_ptr, int k, StripRaw<CH>& raw) {
-    const uint4* p = reinterpret_cast<const uint4*>(row_ptr + (CH == 3 ? 96 : 32) * k);  // 32 px, 16-B aligned
+template <int CH, int S = kS>
+__device__ __forceinline__ void load_strip_raw(const uint8_t* __restrict__ row_ptr, int k, StripRaw<CH, S>& raw) {
+    const uint4* p = reinterpret_cast<const uint4*>(row_ptr + (S * CH) * k);  // S px, 16-B aligned
 #pragma unroll
-    for (int q = 0; q < (CH == 3 ? 6 : 2); ++q) raw.q[q] = p[q];
+    for (int q = 0; q < S * CH / 16; ++q) raw.q[q] = p[q];
 }
 
-template <int CH>
-__device__ __forceinline__ void strip_luma(const StripRaw<CH>& raw, float (&v)[kS]) {
+template <int CH, int S = kS>
+__device__ __forceinline__ void strip_luma(const StripRaw<CH, S>& raw, float (&v)[S]) {
     if (CH == 3) {
-        uint32_t w[24];
+        uint32_t w[S * 3 / 4];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
+        for (int q = 0; q < S * 3 / 16; ++q) {
             const uint4 t = raw.q[q];
             w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
         }
 #pragma unroll
-        for (int c = 0; c < kS; ++c) {
+        for (int c = 0; c < S; ++c) {
             const int b0 = 3 * c, b1 = 3 * c + 1, b2 = 3 * c + 2;
             const float r = (float)((w[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu);
             const float g = (float)((w[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu);
@@ -400,14 +399,14 @@ __device__ __forceinline__ void strip_luma(const StripRaw<CH>& raw, float (&v)[k
             v[c] = yv;
         }
     } else {
-        uint32_t w[8];
+        uint32_t w[S / 4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < S / 16; ++q) {
             const uint4 t = raw.q[q];
             w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
         }
 #pragma unroll
-        for (int c = 0; c < kS; ++c) v[c] = luma_gray((w[c >> 2] >> (8 * (c & 3))) & 0xFFu);
+        for (int c = 0; c < S; ++c) v[c] = luma_gray((w[c >> 2] >> (8 * (c & 3))) & 0xFFu);
     }
 }
 
@@ -487,12 +486,18 @@ __device__ __forceinline__ void column_pass512(float* col, const int stride, flo
 }
 #undef HVD_COL_STEP
 
-template <int CH>
-__global__ __launch_bounds__(512, 4) void k_down512(  // 4 waves/SIMD = 2 workgroups/CU: <= 128 VGPRs
-    const uint8_t* __restrict__ frames, long long n,
-                                                 float* __restrict__ out64) {
-    __shared__ float buf[kF][kBufLd];
-    __shared__ float cs[4][kCsLd];
+// SPLITD: pass D (64 sample columns per frame, but a whole wave's instruction stream per strip when
+// run 4 lanes wide next to B) is left to k_down512_d; C then writes its samples to csamp[frame][j][row].
+// S: strip width (32: 2 workgroups/CU, B on half a wave; 64 (SPLITD only): 1 workgroup/CU, B on a full
+// wave and half as many B phases).
+template <int CH, bool SPLITD, int S>
+__global__ __launch_bounds__(512, (S == 32 ? 4 : 2)) void k_down512(  // S=32: 2 workgroups/CU => <= 128 VGPRs
+    const uint8_t* __restrict__ frames, long long n, float* __restrict__ out64, float* __restrict__ csamp) {
+    static_assert(S == 32 || (S == 64 && SPLITD), "64-column strips need the split D pass (no room for cs)");
+    constexpr int NST = kF / S;       // full strips; strip NST holds the two tail columns
+    constexpr int SPS = S / 8;        // decimation samples per strip
+    __shared__ float buf[kF][S + 1];
+    __shared__ float cs[SPLITD ? 1 : 4][SPLITD ? 1 : kCsLd];
     const int y = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -500,18 +505,19 @@ __global__ __launch_bounds__(512, 4) void k_down512(  // 4 waves/SIMD = 2 workgr
     for (long long f = blockIdx.x; f < n; f += gridDim.x) {
         const uint8_t* row_ptr = frames + (size_t)f * kF * kF * CH + (size_t)y * kF * CH;
         float* dst = out64 + (size_t)f * 4096;
+        float* cg = csamp + (size_t)f * 64 * kF;  // SPLITD: C samples [sample column j][row]
         float sA = 0.0f, lagA[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float sC = 0.0f, lagC[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        StripRaw<CH> raw;
-        load_strip_raw<CH>(row_ptr, 0, raw);
+        StripRaw<CH, S> raw;
+        load_strip_raw<CH, S>(row_ptr, 0, raw);
 
 #pragma unroll 1
-        for (int k = 0; k <= 16; ++k) {
+        for (int k = 0; k <= NST; ++k) {
             // ---------------- A: rep-1 along the row -------------------------------------
-            if (k < 16) {
-                float v[kS];
-                strip_luma<CH>(raw, v);
-                if (k < 15) load_strip_raw<CH>(row_ptr, k + 1, raw);  // in flight during B/C of this strip
+            if (k < NST) {
+                float v[S];
+                strip_luma<CH, S>(raw, v);
+                if (k < NST - 1) load_strip_raw<CH, S>(row_ptr, k + 1, raw);  // in flight during B/C of this strip
                 if (k == 0) {
                     // s = 0,1: accumulate only; s = 2: /3; s = 3: /4 (box1DFloat phases 1-2)
                     sA = __fadd_rn(sA, v[0]);
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(512, 4) void k_down512(  // 4 waves/SIMD = 2 workgr
 #pragma unroll
                     for (int c = 0; c < 4; ++c) lagA[c] = v[c];
 #pragma unroll
-                    for (int c = 4; c < kS; ++c) {
+                    for (int c = 4; c < S; ++c) {
                         sA = __fadd_rn(sA, v[c]);
                         sA = __fsub_rn(sA, lagA[c & 3]);
                         lagA[c & 3] = v[c];
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(512, 4) void k_down512(  // 4 waves/SIMD = 2 workgr
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < kS; ++c) {
+                    for (int c = 0; c < S; ++c) {
                         sA = __fadd_rn(sA, v[c]);
                         sA = __fsub_rn(sA, lagA[c & 3]);
                         lagA[c & 3] = v[c];
@@ -548,55 +554,117 @@ __global__ __launch_bounds__(512, 4) void k_down512(  // 4 waves/SIMD = 2 workgr
             __syncthreads();
 
             // ---------------- B: rep-1 down the buffer columns (in place) ‖ D of strip k-1 ----
-            const int c_lo = (k == 0) ? 2 : 0, c_hi = (k == 16) ? 2 : kS;
+            const int c_lo = (k == 0) ? 2 : 0, c_hi = (k == NST) ? 2 : S;
             if (wave == 0) {
                 const int c = lane;
-                if (c >= c_lo && c < c_hi) column_pass512<true>(&buf[0][c], kBufLd, nullptr, 0);
+                if (c >= c_lo && c < c_hi) column_pass512<true>(&buf[0][c], S + 1, nullptr, 0);
             } else if (wave == 1 && k > 0) {
                 // D: samples written by C of strip k-1: slot jj <-> sample column j = 4(k-1) - 1 + jj
-                const int jj = lane, j = 4 * (k - 1) - 1 + jj;
-                if (jj < 4 && j >= 0 && j < 64) column_pass512<false>(cs[jj], 1, dst, j);
+                const int jj = lane, j = SPS * (k - 1) - 1 + jj;
+                if (!SPLITD && jj < 4 && j >= 0 && j < 64) column_pass512<false>(cs[jj], 1, dst, j);
             }
             __syncthreads();
 
             // ---------------- C: rep-2 along the row over the buffer columns ------------------
-            // buffer column c <-> filter input index t = 32k - 2 + c; ring slot t & 3 = (c + 2) & 3;
+            // buffer column c <-> filter input index t = S*k - 2 + c; ring slot t & 3 = (c + 2) & 3;
             // the output t - 2 is a decimation sample iff c is a multiple of 8 (slot c / 8)
             if (k == 0) {
-                // t = 0..29 <-> c = 2..31
+                // t = 0..S-3 <-> c = 2..S-1
                 const float t0 = buf[y][2], t1 = buf[y][3], t2 = buf[y][4], t3 = buf[y][5];
                 sC = __fadd_rn(__fadd_rn(__fadd_rn(t0, t1), t2), t3);
                 lagC[0] = t0; lagC[1] = t1; lagC[2] = t2; lagC[3] = t3;
 #pragma unroll
-                for (int c = 6; c < kS; ++c) {
+                for (int c = 6; c < S; ++c) {
                     const float x = buf[y][c];
                     sC = __fsub_rn(__fadd_rn(sC, x), lagC[(c + 2) & 3]);
                     lagC[(c + 2) & 3] = x;
-                    if ((c & 7) == 0) cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
+                    if ((c & 7) == 0) {
+                        if (SPLITD) {
+                            if (SPS * k - 1 + (c >> 3) >= 0) cg[(size_t)(SPS * k - 1 + (c >> 3)) * kF + y] = __fmul_rn(sC, 0.25f);
+                        } else {
+                            cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
+                        }
+                    }
                 }
-            } else if (k < 16) {
+            } else if (k < NST) {
 #pragma unroll
-                for (int c = 0; c < kS; ++c) {
+                for (int c = 0; c < S; ++c) {
                     const float x = buf[y][c];
                     sC = __fsub_rn(__fadd_rn(sC, x), lagC[(c + 2) & 3]);
                     lagC[(c + 2) & 3] = x;
-                    if ((c & 7) == 0) cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
+                    if ((c & 7) == 0) {
+                        if (SPLITD) {
+                            if (SPS * k - 1 + (c >> 3) >= 0) cg[(size_t)(SPS * k - 1 + (c >> 3)) * kF + y] = __fmul_rn(sC, 0.25f);
+                        } else {
+                            cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
+                        }
+                    }
                 }
             } else {
                 // t = 510: output 508 = sample column 63 (slot 0); t = 511 feeds nothing that is sampled
                 const float x = buf[y][0];
                 sC = __fsub_rn(__fadd_rn(sC, x), lagC[2]);
-                cs[0][y] = __fmul_rn(sC, 0.25f);
+                if (SPLITD)
+                    cg[(size_t)63 * kF + y] = __fmul_rn(sC, 0.25f);
+                else
+                    cs[0][y] = __fmul_rn(sC, 0.25f);
             }
             __syncthreads();
         }
 
         // D for the last strip's single sample column (j = 63)
-        if (wave == 1 && lane == 0) column_pass512<false>(cs[0], 1, dst, 63);
+        if (!SPLITD && wave == 1 && lane == 0) column_pass512<false>(cs[0], 1, dst, 63);
         __syncthreads();  // cs / buf are reused by the next frame
     }
 }
 
+
+
+// Pass D for SPLITD: one wave per frame, lane = sample column j (64 of them), the 512 rows of
+// csamp[frame][j][.] streamed through LDS in tiles of 64 rows (coalesced loads, conflict-free
+// transposed reads). Only the outputs oy = 8i+4 (step s = 8i+6) are emitted.
+__global__ __launch_bounds__(64) void k_down512_d(const float* __restrict__ csamp, long long n,
+                                                  float* __restrict__ out64) {
+    __shared__ float tile[64][65];
+    const int j = threadIdx.x;
+    for (long long f = blockIdx.x; f < n; f += gridDim.x) {
+        const float* src = csamp + (size_t)f * 64 * kF;
+        float* dst = out64 + (size_t)f * 4096;
+        float sum = 0.0f, l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, l3 = 0.0f;
+#pragma unroll 1
+        for (int y0 = 0; y0 < kF; y0 += 64) {
+            __syncthreads();
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c) tile[c][j] = src[(size_t)c * kF + y0 + j];  // row c of the tile = column c
+            __syncthreads();
+            const float* col = &tile[j][0];
+            if (y0 == 0) {
+                const float x0 = col[0], x1 = col[1], x2 = col[2], x3 = col[3];
+                sum = __fadd_rn(__fadd_rn(__fadd_rn(x0, x1), x2), x3);
+                l0 = x0; l1 = x1; l2 = x2; l3 = x3;
+#pragma unroll
+                for (int q = 4; q < 64; q += 4) {
+                    const float a0 = col[q], a1 = col[q + 1], a2 = col[q + 2], a3 = col[q + 3];
+                    sum = __fsub_rn(__fadd_rn(sum, a0), l0); l0 = a0;
+                    sum = __fsub_rn(__fadd_rn(sum, a1), l1); l1 = a1;
+                    sum = __fsub_rn(__fadd_rn(sum, a2), l2); l2 = a2;
+                    if ((q & 7) == 4) dst[((q - 4) >> 3) * 64 + j] = __fmul_rn(sum, 0.25f);  // step q+2 = 8i+6
+                    sum = __fsub_rn(__fadd_rn(sum, a3), l3); l3 = a3;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 64; q += 4) {
+                    const float a0 = col[q], a1 = col[q + 1], a2 = col[q + 2], a3 = col[q + 3];
+                    sum = __fsub_rn(__fadd_rn(sum, a0), l0); l0 = a0;
+                    sum = __fsub_rn(__fadd_rn(sum, a1), l1); l1 = a1;
+                    sum = __fsub_rn(__fadd_rn(sum, a2), l2); l2 = a2;
+                    if ((q & 7) == 4) dst[((y0 + q - 4) >> 3) * 64 + j] = __fmul_rn(sum, 0.25f);
+                    sum = __fsub_rn(__fadd_rn(sum, a3), l3); l3 = a3;
+                }
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------
 // k_down512s: systolic form of the fused 512x512 down-sampler.
@@ -891,6 +959,8 @@ static int jarosz_window(int dim) { return (dim + 2 * 64 - 1) / (2 * 64); }
 // Workspace (floats per frame) the down-sampler needs besides the 64x64 output.
 size_t pdq_downsample_ws_floats(int h, int w) { return 2 * (size_t)h * w + (size_t)64 * h; }
 
+bool g_pdq_down512_strip64 = false;    // with split D: 64-column strips, 1 workgroup/CU
+bool g_pdq_down512_split_d = false;    // A/B switch: pass D as its own kernel (k_down512_d); same speed
 bool g_pdq_down512_systolic = false;  // A/B switch: k_down512s instead of k_down512
 bool g_pdq_fused_down512 = true;  // A/B switch (hvd_debug_set "pdq_fused_down512")
 
@@ -905,10 +975,32 @@ hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int 
                 hipLaunchKernelGGL(k_down512s<3>, dim3(gs), dim3(kNW * 64), 0, s, d_frames, (long long)n, d_out64);
             else
                 hipLaunchKernelGGL(k_down512s<1>, dim3(gs), dim3(kNW * 64), 0, s, d_frames, (long long)n, d_out64);
+        } else if (g_pdq_down512_split_d) {
+            // d_ws holds the C samples (64 x 512 floats per frame); the workspace is sized for min(n, 1024)
+            // frames of the generic path (>= 17 x that many frames here), so go slab by slab
+            const int64_t slab = 16384;
+            for (int64_t f0 = 0; f0 < n; f0 += slab) {
+                const int64_t m = (n - f0) < slab ? (n - f0) : slab;
+                const uint8_t* src = d_frames + (size_t)f0 * kF * kF * channels;
+                float* o64 = d_out64 + (size_t)f0 * 4096;
+                const unsigned g1 = (unsigned)(m < 512 ? m : 512);
+                if (g_pdq_down512_strip64) {
+                    const unsigned g64 = (unsigned)(m < 256 ? m : 256);  // one workgroup per CU (133 KB of LDS)
+                    if (channels == 3)
+                        hipLaunchKernelGGL((k_down512<3, true, 64>), dim3(g64), dim3(512), 0, s, src, (long long)m, o64, d_ws);
+                    else
+                        hipLaunchKernelGGL((k_down512<1, true, 64>), dim3(g64), dim3(512), 0, s, src, (long long)m, o64, d_ws);
+                } else if (channels == 3)
+                    hipLaunchKernelGGL((k_down512<3, true, 32>), dim3(g1), dim3(512), 0, s, src, (long long)m, o64, d_ws);
+                else
+                    hipLaunchKernelGGL((k_down512<1, true, 32>), dim3(g1), dim3(512), 0, s, src, (long long)m, o64, d_ws);
+                const unsigned g2 = (unsigned)(m < 256 * 16 ? m : 256 * 16);
+                hipLaunchKernelGGL(k_down512_d, dim3(g2), dim3(64), 0, s, (const float*)d_ws, (long long)m, o64);
+            }
         } else if (channels == 3)
-            hipLaunchKernelGGL(k_down512<3>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+            hipLaunchKernelGGL((k_down512<3, false, 32>), dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64, d_ws);
         else
-            hipLaunchKernelGGL(k_down512<1>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+            hipLaunchKernelGGL((k_down512<1, false, 32>), dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64, d_ws);
         return hipGetLastError();
     }
     if (jarosz_window(h) > kTW || jarosz_window(w) > kTW) return hipErrorInvalidValue;

@@ -16,9 +16,14 @@ d_f = L.DeviceBuffer.from_array(fr); d_s = L.DeviceBuffer(sb.value); d_h = L.Dev
 gray = synth.frames_gray(8, seed=9, h=512, w=512)
 hg, qg = hvd_amd.vpdq.hash_frames(gray); hgo, qgo = O.hash_frames(gray, num_threads=8)
 print("gray512 parity:", np.array_equal(hg, hgo), np.array_equal(qg, qgo))
-for fused in (0, 1, 2):
+for fused in (0, 1, 2, 3, 4):
   L.check(lib.hvd_debug_set(b"pdq_fused_down512", 1 if fused else 0))
   L.check(lib.hvd_debug_set(b"pdq_down512_systolic", 1 if fused == 2 else 0))
+  L.check(lib.hvd_debug_set(b"pdq_down512_split_d", 1 if fused >= 3 else 0))
+  L.check(lib.hvd_debug_set(b"pdq_down512_strip64", 1 if fused == 4 else 0))
+  if fused >= 3:
+      hg, qg = hvd_amd.vpdq.hash_frames(gray)
+      print("gray512 split-D parity:", np.array_equal(hg, hgo), np.array_equal(qg, qgo))
   if fused == 2:
       hg, qg = hvd_amd.vpdq.hash_frames(gray)
       print("gray512 systolic parity:", np.array_equal(hg, hgo), np.array_equal(qg, qgo))
