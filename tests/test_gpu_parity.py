@@ -494,3 +494,92 @@ def test_k1_down512_all_forms_agree(gpu, hvd, oracle):
     finally:
         for k_, v_ in zip(keys, (1, 0, 0, 0)):
             gpu.check(lib.hvd_debug_set(k_, v_))
+
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_differential_sweep(gpu, hvd, oracle, seed):
+    """Seeded random shapes around the padding / tile / super-panel boundaries (127, 128, 1023,
+    1024, 1025, 2047 ...), random tolerances, group maps, rank splits and query x target shapes:
+    every GPU entry point against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    edges = np.array([2, 31, 32, 33, 127, 128, 129, 255, 257, 1023, 1024, 1025, 2047, 2049, 3000, 4097, 5555])
+    n = int(rng.choice(edges)) + int(rng.integers(0, 3))
+    md = int(rng.choice([0, 5, 31, 31, 31, 40, 63, 64, 90, 127, 128, 200]))
+    db, _ = hvd.synth.hash_db(n, seed=2000 + seed, plant_fraction=0.05, max_flips=int(min(2 * md + 8, 200)))
+    grp = None
+    if rng.random() < 0.5:
+        grp = rng.integers(0, max(2, n // int(rng.integers(1, 9))), n).astype(np.int32)
+    want = oracle.allpairs(db, md, group=grp, cap=max(n * n // 2, 16), num_threads=8)
+    # host entry (default kernel)
+    assert np.array_equal(hvd.allpairs_hamming(db, md, group=grp), want)
+    # every device variant
+    for variant in (0, 1, 3, 8, 9, 10, 11):
+        assert np.array_equal(_run_variant(gpu, hvd, db, variant, max_dist=md, group=grp, cap=max(len(want), 16)), want), variant
+    # rank split of the default kernel
+    world = int(rng.integers(2, 6))
+    d_db = gpu.DeviceBuffer.from_array(db)
+    d_grp = gpu.DeviceBuffer.from_array(grp) if grp is not None else None
+    parts = [hvd.multigpu.sharded_allpairs(d_db.ptr, n, r, world, None, max_dist=md,
+                                           d_group_ptr=d_grp.ptr if d_grp else None) for r in range(world)]
+    assert np.array_equal(hvd.multigpu.merge_pairs(parts), want)
+    # video level, ragged, and the query x target form against per-pair matching
+    V = int(rng.integers(2, 120))
+    frames, offsets, _ = hvd.synth.video_hashes(V, seed=3000 + seed, frames_per_video=(0, int(rng.integers(1, 40))),
+                                                copy_fraction=0.3)
+    assert np.array_equal(hvd.match_videos(frames, offsets, 31), oracle.match_videos(frames, offsets, 31))
+    q_sel = rng.choice(V, size=int(rng.integers(1, V + 1)), replace=False)
+    blobs = [frames[offsets[p]:offsets[p + 1]] for p in q_sel]
+    fq = np.concatenate(blobs) if sum(len(b) for b in blobs) else np.zeros((0, 32), np.uint8)
+    oq = np.zeros(len(blobs) + 1, np.int64)
+    np.cumsum([len(b) for b in blobs], out=oq[1:])
+    got = hvd.search.match_videos_cross(fq, oq, frames, offsets, q_sel.astype(np.int32), np.arange(V, dtype=np.int32))
+    want_x = []
+    for a, p in enumerate(q_sel):
+        for b in range(V):
+            if b == p:
+                continue
+            qh, th = oracle.match_two(frames[offsets[p]:offsets[p + 1]].tobytes(),
+                                      frames[offsets[b]:offsets[b + 1]].tobytes(), 31)
+            if qh or th:
+                want_x.append((a, b, qh, th))
+    assert np.array_equal(got, np.array(want_x, dtype=gpu.VMATCH_DTYPE))
+    # frames: a random geometry through both entries
+    h, w = int(rng.choice([64, 65, 96, 128, 200, 512])), int(rng.choice([64, 70, 128, 333, 512]))
+    nfr = int(rng.integers(1, 9))
+    fr = hvd.synth.frames_rgb(nfr, seed=4000 + seed, h=h, w=w) if rng.random() < 0.5 else \
+        hvd.synth.frames_gray(nfr, 4000 + seed, h, w)
+    hh, qq = hvd.vpdq.hash_frames(fr)
+    ho, qo = oracle.hash_frames(fr, num_threads=4)
+    assert np.array_equal(hh, ho) and np.array_equal(qq, qo), (h, w, fr.shape)
+
+
+def test_entry_points_from_a_worker_thread(gpu, hvd, oracle):
+    """The reference drives this path from a QThread worker (gui/gui.py:195-237): hashing, matching
+    and searching must work from a thread other than the one that called hvd_init."""
+    import threading
+
+    fr = hvd.synth.frames_gray(64, seed=93)
+    db, _ = hvd.synth.hash_db(3000, seed=94, plant_fraction=0.02)
+    out = {}
+
+    def work():
+        try:
+            out["h"] = hvd.vpdq.hash_frames(fr)
+            out["p"] = hvd.allpairs_hamming(db, 31)
+            hs = hvd.VideoHasher(1, 64, 64, 0)
+            for f in fr:
+                hs.hash_frame(f)
+            out["v"] = hs.finish()
+            out["m"] = hvd.matchHashBytes(db[:10].tobytes(), db[:10].tobytes(), 31)
+        except Exception as exc:  # surfaced below
+            out["err"] = exc
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert "err" not in out, out.get("err")
+    ho, qo = oracle.hash_frames(fr)
+    assert np.array_equal(out["h"][0], ho) and np.array_equal(out["h"][1], qo)
+    assert np.array_equal(out["p"], oracle.allpairs(db, 31))
+    assert out["v"].bytes == ho[qo >= 31].tobytes() and out["m"] == 100.0
