@@ -35,6 +35,29 @@ BYTES_PER_COMPARISON = 64      # two 32-byte operands, no reuse credited (SURVEY
 BYTES_PER_FRAME_64 = 4096 + 32 + 4
 
 
+def host_threads() -> int:
+    """Threads for the CPU baseline: os.cpu_count() bounded by the affinity mask and the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,7 +338,7 @@ def main():
         if not args.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
 
-            cores = os.cpu_count() or 1
+            cores = host_threads()
             # bounded sample of the same workload: calibrate, then ~cpu-seconds of work
             n0 = min(n, 150_000)  # big enough that thread start-up does not dominate on many-core hosts
             O.allpairs_count(db[:n0], 31, num_threads=cores)  # warm: page in, spawn once
@@ -348,6 +371,7 @@ def main():
                    "sample": f"oracle (C, popcnt, pthreads) all-pairs over the first {ns} of the {n} hashes "
                              f"({ns * (ns - 1) // 2:.3g} comparisons, {dt:.1f} s)",
                    "value_1thread": float(f"{cpu_cmp_1t:.4g}"),
+                   "speedup_over_1thread": round(cpu_cmp / cpu_cmp_1t, 1), "os_cpu_count": os.cpu_count(),
                    "frames_per_s": float(f"{args.frames / dtf:.4g}"),
                    "frames_sample": f"oracle PDQ over the same {args.frames} frames, {cores} threads, {dtf:.2f} s",
                    "note": "the reference's real CPU path (hvdaccelerators 0.4.0) is not installable offline; this "
