@@ -148,3 +148,39 @@ def test_synth_is_deterministic(hvd):
     f1 = hvd.synth.frames_gray(5, seed=4)
     f2 = hvd.synth.frames_gray(5, seed=4)
     assert np.array_equal(f1, f2) and f1.shape == (5, 64, 64)
+
+
+def test_vpdqhash_text_forms_and_hash_semantics(hvd):
+    H = hvd.VpdqHash
+    raw = bytes(range(32)) * 3
+    a = H(raw)
+    assert H.from_string(raw.hex().upper()) == a          # hex case does not matter
+    assert H.from_string("  " + raw.hex() + "\r\n") == a   # surrounding whitespace from file.read()
+    assert a.frames().shape == (3, 32) and a.frames().tobytes() == raw
+    assert len({a, H(raw), H(raw[:32])}) == 2             # usable as a dict/set key, value semantics
+    assert H(bytearray(raw)) == a and H(memoryview(raw)) == a
+    assert repr(a) == "VpdqHash(frames=3)"
+    assert (a == raw) is False                            # only equal to another VpdqHash
+    with pytest.raises(ValueError):
+        H.from_string(raw.hex()[:-2])                     # not a whole number of frames
+
+
+def test_similarity_of_records_direction_rules(hvd):
+    """The reference discovers {A,B} from A's search or from B's (dedup.py:468-482): asymmetric
+    policies therefore take the better direction, the symmetric one the minimum."""
+    from hvd_amd._lib import VMATCH_DTYPE
+
+    recs = np.array([(0, 1, 10, 2)], dtype=VMATCH_DTYPE)
+    lengths = np.array([10, 20])
+    f = hvd.search.similarity_of_records
+    assert f(recs, lengths, "min")[0] == 10.0      # min(100 %, 10 %)
+    assert f(recs, lengths, "query")[0] == 100.0   # A as query: 10/10; B as query: 2/20 -> best 100
+    assert f(recs, lengths, "target")[0] == 100.0
+    assert f(recs, lengths, "max")[0] == 100.0
+    with pytest.raises(ValueError):
+        f(recs, lengths, "mean")
+
+
+def test_find_potential_duplicates_rejects_bad_blobs_before_touching_the_gpu(hvd):
+    with pytest.raises(ValueError):
+        hvd.find_potential_duplicates([b"\0" * 32, b"\0" * 31])
