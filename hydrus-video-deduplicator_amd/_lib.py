@@ -53,6 +53,8 @@ SIGNATURES = {
     "hvd_memcpy_h2d": (_int, [_vp, _vp, _sz]),
     "hvd_memcpy_d2h": (_int, [_vp, _vp, _sz]),
     "hvd_dev_sync": (_int, []),
+    "hvd_set_pdq_dct_mode": (_int, [_int]),
+    "hvd_get_pdq_dct_mode": (_int, []),
     "hvd_debug_set": (_int, [C.c_char_p, _int]),
     "hvd_pdq_scratch_bytes": (_int, [_i64, _int, _int, _int, C.POINTER(_sz)]),
     "hvd_dev_pdq_hash_frames": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),

@@ -172,6 +172,11 @@ int hvd_init(int device) {
     fill_dct(g.h_dct);
     HIP_TRY(hipMalloc((void**)&g.d_dct, sizeof g.h_dct));
     HIP_TRY(hipMemcpy(g.d_dct, g.h_dct, sizeof g.h_dct, hipMemcpyHostToDevice));
+    if (const char* m = getenv("HVD_PDQ_DCT_MODE")) {  // same switch as hvd_set_pdq_dct_mode()
+        if (!strcmp(m, "fma") || !strcmp(m, "1")) hvd::g_pdq_dct_mode = HVD_DCT_FMA;
+        else if (!strcmp(m, "strict") || !strcmp(m, "0") || !*m) hvd::g_pdq_dct_mode = HVD_DCT_STRICT;
+        else return fail(HVD_ERR_ARG, "HVD_PDQ_DCT_MODE=%s: expected strict or fma", m);
+    }
     g.device = device;
     g.ready = true;
     return HVD_OK;
@@ -252,6 +257,14 @@ int hvd_timer_stop(float* out_ms) {
     HIP_TRY(hipEventElapsedTime(out_ms, g.ev0, g.ev1));
     return HVD_OK;
 }
+
+int hvd_set_pdq_dct_mode(int mode) {
+    if (mode != HVD_DCT_STRICT && mode != HVD_DCT_FMA) return fail(HVD_ERR_ARG, "unknown DCT mode %d", mode);
+    hvd::g_pdq_dct_mode = mode;
+    return HVD_OK;
+}
+
+int hvd_get_pdq_dct_mode(void) { return hvd::g_pdq_dct_mode; }
 
 int hvd_debug_set(const char* key, int value) {
     if (!key) return fail(HVD_ERR_ARG, "key is NULL");

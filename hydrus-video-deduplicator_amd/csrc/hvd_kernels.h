@@ -44,6 +44,7 @@ hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_
 // down-sampler). d_in strides are implied by kind.
 extern bool g_pdq_dct_from_lds;
 extern int g_pdq_luma_lut;
+extern int g_pdq_dct_mode;
 extern bool g_pdq_fused_down512;
 extern bool g_pdq_down512_systolic;
 extern bool g_pdq_down512_split_d;

@@ -64,6 +64,14 @@ __device__ __forceinline__ void grad_term(float u, float v, float& acc_m, int& a
     acc_c += (r >= 255.0f) ? 1 : 0;
 }
 
+// Lane l reads lane l+1 of the whole 64-lane wave (lane 63 reads 0 and is ignored by callers): the DPP
+// wave_shl:1 control of the GFX9 family, which folds into the consuming VALU instruction instead
+// of a trip through the LDS crossbar (ds_bpermute).
+__device__ __forceinline__ float wave_next_lane(float v) {
+    const int x = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {  // exact: integer-valued, far below 2^24
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
 #pragma unroll
             for (int k = 0; k < 63; ++k) grad_term(a[k], a[k + 1], gs, cs_);
 #pragma unroll
-            for (int k = 0; k < 64; ++k) grad_term(a[k], __shfl_down(a[k], 1, 64), gh, ch_);
+            for (int k = 0; k < 64; ++k) grad_term(a[k], wave_next_lane(a[k]), gh, ch_);
             if (lane < 63) {  // column 63 has no right neighbour
                 gs += gh;
                 cs_ += ch_;
@@ -232,6 +240,157 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             }
         }
         __syncthreads();  // T is rewritten by the next trip
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_pdq_hash64_fma: the same frame hash with the DCT on the matrix cores ("fma" DCT mode).
+//
+// v_mfma_f32_16x16x4_f32 is bit for bit a k-ordered fmaf chain (one rounding per multiply-add),
+// i.e. exactly what upstream's `sumk += D*A` becomes when the compiler contracts it -- the
+// numerics of its arm64 wheels, NOT of the x86-64 ones (those are the default "strict" mode
+// above). The mode is opt-in (hvd_set_pdq_dct_mode) and is held to the same standard: bit-exact
+// against the oracle's fma mode.
+//   stage 1  T(16x64) = D(16x64) * A(64x64): per 16-column block nb, 16 MFMAs over k;
+//            A operand = D[i = lane&15][k = 4ks + (lane>>4)] (constant, 16 VGPRs per wave),
+//            B operand = luma(row 4ks + (lane>>4), column 16nb + (lane&15))
+//   stage 2  B(16x16) = T * D^T: A operand = T[i = lane&15][k] (through LDS), B operand = the same
+//            D fragments; output B[i = 4(lane>>4) + r][j = lane&15]
+// Quality, median and bit extraction are shared with the strict kernel (the quality needs the
+// column-per-lane view, so the frame bytes are read in both layouts; they are L1-hot).
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_pdq_hash64_fma(const void* __restrict__ in, long long n,
+                                                        const float* __restrict__ dct, uint8_t* __restrict__ hashes,
+                                                        int32_t* __restrict__ quality) {
+    __shared__ PdqLds lds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g4 = lane >> 4, c16 = lane & 15;
+
+    lds.luma_lut[threadIdx.x] = luma_gray(threadIdx.x);
+    float dfrag[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) dfrag[ks] = dct[c16 * 64 + 4 * ks + g4];
+    __syncthreads();
+
+    const long long groups = (n + kWaves - 1) / kWaves;
+    for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
+        const long long f = g * kWaves + wave;
+        const bool valid = f < n;  // wave-uniform
+        float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+        if (valid) {
+            // ---- quality: column `lane` of the frame, as in the strict kernel ---------------------
+            {
+                float a[64];
+                if (KIND == 0) {
+                    const uint8_t* src = reinterpret_cast<const uint8_t*>(in) + f * 4096 + lane;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) a[k] = lds.luma_lut[src[k * 64]];
+                } else {
+                    const float* src = reinterpret_cast<const float*>(in) + f * 4096 + lane;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) a[k] = src[k * 64];
+                }
+                float gs = 0.0f, gh = 0.0f;
+                int cs_ = 0, ch_ = 0;
+#pragma unroll
+                for (int k = 0; k < 63; ++k) grad_term(a[k], a[k + 1], gs, cs_);
+#pragma unroll
+                for (int k = 0; k < 64; ++k) grad_term(a[k], wave_next_lane(a[k]), gh, ch_);
+                if (lane < 63) {
+                    gs += gh;
+                    cs_ += ch_;
+                }
+                const int gsum = (int)wave_sum_f32(gs + (float)cs_);
+                int qual = gsum / 90;
+                qual = qual > 100 ? 100 : qual;
+                if (lane == 0) quality[f] = qual;
+            }
+
+            // ---- stage 1 on the matrix cores --------------------------------------------------------
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float af[16];
+                if (KIND == 0) {
+                    const uint8_t* src = reinterpret_cast<const uint8_t*>(in) + f * 4096 + g4 * 64 + 16 * nb + c16;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) af[ks] = lds.luma_lut[src[ks * 256]];
+                } else {
+                    const float* src = reinterpret_cast<const float*>(in) + f * 4096 + g4 * 64 + 16 * nb + c16;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) af[ks] = src[ks * 256];
+                }
+                v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dfrag[ks], af[ks], acc, 0, 0, 0);
+                // C/D layout: column = lane&15, row = 4*(lane>>4) + r  ->  T[i = 4 g4 + r][j = 16 nb + c16]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds.T[wave][4 * g4 + r][16 * nb + c16] = acc[r];
+            }
+        }
+        __syncthreads();
+
+        if (valid) {
+            // ---- stage 2 on the matrix cores: A operand T[i = c16][k = 4ks + g4] ----------------------
+            v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds.T[wave][c16][4 * ks + g4], dfrag[ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[r] = acc[r];  // B[i = 4 g4 + r][j = c16]
+
+            // ---- median (same radix select as the strict kernel) ---------------------------------------
+            uint32_t key[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t u = __float_as_uint(b[r]);
+                key[r] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            }
+            uint32_t prefix = 0, mask = 0;
+            int kth = 128, remaining = 256;
+#pragma unroll 1
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t bsel = 1u << bit;
+                const uint32_t m2 = mask | bsel;
+                int cnt0 = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cnt0 += __popcll(__ballot((key[r] & m2) == prefix));
+                if (kth > cnt0) {
+                    kth -= cnt0;
+                    remaining -= cnt0;
+                    prefix |= bsel;
+                } else {
+                    remaining = cnt0;
+                }
+                mask = m2;
+                if (remaining == 1) break;
+            }
+            if (mask != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned long long bm = __ballot((key[r] & mask) == prefix);
+                    if (bm) prefix = __builtin_amdgcn_readlane(key[r], (int)__builtin_ctzll(bm));
+                }
+            }
+            const uint32_t mu = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
+            const float med = __uint_as_float(mu);
+
+            // ---- bits: lane (g4, c16), output r is coefficient (4 g4 + r, c16) = hash bit 64 g4 + 16 r + c16:
+            //      64-bit word w of the hash takes 16 bits from each of the four ballots
+            unsigned long long m[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = __ballot(b[r] > med);
+            if (lane < 4) {
+                const int sh = 16 * lane;
+                const unsigned long long w = ((m[0] >> sh) & 0xFFFFull) | (((m[1] >> sh) & 0xFFFFull) << 16) |
+                                             (((m[2] >> sh) & 0xFFFFull) << 32) | (((m[3] >> sh) & 0xFFFFull) << 48);
+                reinterpret_cast<unsigned long long*>(hashes)[f * 4 + lane] = w;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -930,6 +1089,7 @@ __global__ __launch_bounds__(kNW * 64) void k_down512s(const uint8_t* __restrict
 
 namespace hvd {
 
+int g_pdq_dct_mode = 0;           // 0: strict mul-then-add on the VALU (default); 1: fma chain on the matrix cores
 int g_pdq_luma_lut = 1;           // 0: compute luma, 1: LDS table, 2: LDS table, loads in groups of 16
 bool g_pdq_dct_from_lds = false;  // A/B switch (hvd_debug_set): stage-1 DCT operand from LDS vs SGPR; measured equal
 
@@ -939,6 +1099,13 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
     const int64_t groups = (n + kWaves - 1) / kWaves;
     const int64_t max_grid = 256 * 7;  // 7 workgroups/CU fit by LDS (21.8 KB each)
     dim3 grid((unsigned)(groups < max_grid ? groups : max_grid));
+    if (g_pdq_dct_mode == 1) {
+        if (kind == 0)
+            hipLaunchKernelGGL(k_pdq_hash64_fma<0>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+        else
+            hipLaunchKernelGGL(k_pdq_hash64_fma<1>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
+        return hipGetLastError();
+    }
     const bool dlds = g_pdq_dct_from_lds;
     const int lut = g_pdq_luma_lut;
 #define HVD_K1(KIND, D, L) hipLaunchKernelGGL((k_pdq_hash64<KIND, D, L>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality)

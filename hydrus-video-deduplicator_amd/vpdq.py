@@ -37,6 +37,20 @@ MATCH_POLICY = os.environ.get("HVD_MATCH_POLICY", "min")
 _POLICIES = ("min", "max", "query", "target")
 
 
+def set_dct_mode(mode: str) -> None:
+    """"strict" (default): separately rounded multiply and add, the numerics of upstream's x86-64
+    builds; "fma": fused multiply-add on the matrix cores, the numerics of upstream's arm64 builds
+    (opt-in; ~2 % of hash bits differ between the two). See include/hvd_mi355x.h."""
+    modes = {"strict": 0, "fma": 1}
+    if mode not in modes:
+        raise ValueError(f"unknown DCT mode {mode!r}; expected one of {sorted(modes)}")
+    _lib.check(_lib.load().hvd_set_pdq_dct_mode(modes[mode]))
+
+
+def get_dct_mode() -> str:
+    return ("strict", "fma")[_lib.load().hvd_get_pdq_dct_mode()]
+
+
 def percent_from_hits(q_hits: int, t_hits: int, nq: int, nt: int, policy: str | None = None) -> float:
     """vPDQ match percentage from the kernel's two counters (either side empty -> 0.0,
     db/DedupeDB.py:555-557)."""

@@ -136,6 +136,17 @@ int hvd_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int hvd_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 int hvd_dev_sync(void);
 
+/* DCT accumulation mode of the frame hash. HVD_DCT_STRICT (default): every `sum += D*A` is a
+ * separately rounded multiply and add -- the numerics of upstream's x86-64 builds and of the
+ * oracle's default mode. HVD_DCT_FMA (opt-in): one fused multiply-add per step, executed by
+ * v_mfma_f32_16x16x4_f32 -- the numerics upstream has where the compiler contracts that statement
+ * (its arm64 builds); bit-exact against the oracle's fma mode, about 2 % of hash bits differ from
+ * the strict mode. Quality values do not depend on the mode. Process-wide. */
+#define HVD_DCT_STRICT 0
+#define HVD_DCT_FMA 1
+int hvd_set_pdq_dct_mode(int mode);
+int hvd_get_pdq_dct_mode(void);
+
 /* Developer switches for A/B measurements ("pdq_dct_from_lds": 0|1). Results never change. */
 int hvd_debug_set(const char* key, int value);
 

@@ -171,16 +171,29 @@ const float* hvd_cpu_dct_matrix(void) {
     return g_dct;
 }
 
-/* pdqhashing.cpp dct64To16: T = D*A (16x64), B = T*D^T (16x16); k-sequential
- * mul-then-add, no contraction. */
+/* DCT accumulation mode. 0 ("strict", default): `sumk += D*A` as a separately rounded multiply and
+ * add -- what upstream's x86-64 wheels compute (baseline x86-64 has no FMA to contract into).
+ * 1 ("fma"): the same statement contracted into one fused multiply-add per step, which is what
+ * clang emits for it on arm64 (-ffp-contract=on is its default) -- upstream's macOS arm64 wheels
+ * (uv.lock:186-206 lists them). The GPU library offers the same two modes. */
+static int g_dct_fma = 0;
+void hvd_cpu_set_dct_mode(int fma) { g_dct_fma = fma != 0; }
+int hvd_cpu_get_dct_mode(void) { return g_dct_fma; }
+
+/* pdqhashing.cpp dct64To16: T = D*A (16x64), B = T*D^T (16x16); k-sequential. */
 static void dct64to16(const float* A, float* T, float* B) {
     const float* D = hvd_cpu_dct_matrix();
+    const int fma = g_dct_fma;
     for (int i = 0; i < 16; ++i)
         for (int j = 0; j < 64; ++j) {
             float s = 0.0f;
             for (int k = 0; k < 64; ++k) {
-                float p = D[i * 64 + k] * A[k * 64 + j];
-                s = s + p;
+                if (fma) {
+                    s = fmaf(D[i * 64 + k], A[k * 64 + j], s);
+                } else {
+                    float p = D[i * 64 + k] * A[k * 64 + j];
+                    s = s + p;
+                }
             }
             T[i * 64 + j] = s;
         }
@@ -188,8 +201,12 @@ static void dct64to16(const float* A, float* T, float* B) {
         for (int j = 0; j < 16; ++j) {
             float s = 0.0f;
             for (int k = 0; k < 64; ++k) {
-                float p = T[i * 64 + k] * D[j * 64 + k];
-                s = s + p;
+                if (fma) {
+                    s = fmaf(T[i * 64 + k], D[j * 64 + k], s);
+                } else {
+                    float p = T[i * 64 + k] * D[j * 64 + k];
+                    s = s + p;
+                }
             }
             B[i * 16 + j] = s;
         }

@@ -45,6 +45,8 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)
             fn.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             fn.restype = C.c_int
+        L.hvd_cpu_set_dct_mode.argtypes = [C.c_int]
+        L.hvd_cpu_set_dct_mode.restype = None
         L.hvd_cpu_hamming256.argtypes = [C.c_void_p, C.c_void_p]
         L.hvd_cpu_hamming256.restype = C.c_int
         L.hvd_cpu_allpairs_hamming256_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
@@ -66,8 +68,9 @@ def dct_matrix() -> np.ndarray:
     return np.ctypeslib.as_array(p, shape=(16, 64)).copy()
 
 
-def hash_frames(frames: np.ndarray, num_threads: int = 1, want_coeffs: bool = False):
-    """frames: uint8[n,h,w] (gray) or uint8[n,h,w,3] (rgb24) -> (hashes u8[n,32], quality i32[n][, coeffs f32[n,256]])."""
+def hash_frames(frames: np.ndarray, num_threads: int = 1, want_coeffs: bool = False, fma: bool = False):
+    """frames: uint8[n,h,w] (gray) or uint8[n,h,w,3] (rgb24) -> (hashes u8[n,32], quality i32[n][, coeffs f32[n,256]]).
+    fma: DCT accumulation by fused multiply-add (upstream's arm64 numerics) instead of mul-then-add."""
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     if frames.ndim == 3:
         fn = lib().hvd_cpu_pdq_hash_frames_gray_u8
@@ -79,8 +82,12 @@ def hash_frames(frames: np.ndarray, num_threads: int = 1, want_coeffs: bool = Fa
     hashes = np.zeros((n, 32), dtype=np.uint8)
     quality = np.zeros(n, dtype=np.int32)
     coeffs = np.zeros((n, 256), dtype=np.float32) if want_coeffs else None
-    rc = fn(frames.ctypes.data, n, h, w, hashes.ctypes.data, quality.ctypes.data,
-            coeffs.ctypes.data if want_coeffs else None, num_threads)
+    lib().hvd_cpu_set_dct_mode(1 if fma else 0)
+    try:
+        rc = fn(frames.ctypes.data, n, h, w, hashes.ctypes.data, quality.ctypes.data,
+                coeffs.ctypes.data if want_coeffs else None, num_threads)
+    finally:
+        lib().hvd_cpu_set_dct_mode(0)
     if rc != 0:
         raise RuntimeError(f"oracle hash_frames rc={rc}")
     return (hashes, quality, coeffs) if want_coeffs else (hashes, quality)

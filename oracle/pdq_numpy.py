@@ -107,7 +107,36 @@ def quality(a64: np.ndarray) -> int:
     return min(g // 90, 100)
 
 
-def dct16(a64: np.ndarray) -> np.ndarray:
+def _fma32(a: np.ndarray, b: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """Elementwise float32 fused multiply-add with ONE rounding, without calling libm: a*b is
+    exact in float64 (24+24 significant bits); the exact sum of that product and c is obtained with
+    an error-free TwoSum in float64 and rounded to float32 once, breaking double-rounding ties with
+    the sign of the residual."""
+    p = a.astype(np.float64) * b.astype(np.float64)
+    c64 = c.astype(np.float64)
+    s = p + c64
+    bb = s - p
+    err = (p - (s - bb)) + (c64 - bb)            # s + err == p + c exactly
+    r = s.astype(np.float32)
+    # s may sit exactly half-way between two floats while the true sum does not: nudge by the residual
+    lo = np.nextafter(r, np.float32(-np.inf))
+    hi = np.nextafter(r, np.float32(np.inf))
+    mid_lo = (lo.astype(np.float64) + r.astype(np.float64)) / 2
+    mid_hi = (hi.astype(np.float64) + r.astype(np.float64)) / 2
+    r = np.where((s == mid_lo) & (err < 0), lo, r)   # rounded up from an exact tie but the true value is below it
+    r = np.where((s == mid_hi) & (err > 0), hi, r)
+    return r.astype(np.float32)
+
+
+def dct16(a64: np.ndarray, fma: bool = False) -> np.ndarray:
+    if fma:
+        t = np.zeros((16, 64), dtype=np.float32)
+        for k in range(64):
+            t = _fma32(np.broadcast_to(_D[:, k : k + 1], (16, 64)), np.broadcast_to(a64[k : k + 1, :], (16, 64)), t)
+        b = np.zeros((16, 16), dtype=np.float32)
+        for k in range(64):
+            b = _fma32(np.broadcast_to(t[:, k : k + 1], (16, 16)), np.broadcast_to(_D[:, k][None, :], (16, 16)), b)
+        return b
     t = np.zeros((16, 64), dtype=np.float32)
     for k in range(64):
         t = t + _D[:, k : k + 1] * a64[k : k + 1, :]
@@ -117,23 +146,23 @@ def dct16(a64: np.ndarray) -> np.ndarray:
     return b
 
 
-def hash_from_luma(luma: np.ndarray) -> tuple[bytes, int, np.ndarray]:
+def hash_from_luma(luma: np.ndarray, fma: bool = False) -> tuple[bytes, int, np.ndarray]:
     """-> (32-byte hash, quality, 16x16 DCT coefficients)."""
     h, w = luma.shape
     a64 = luma.astype(np.float32) if (h, w) == (64, 64) else jarosz_decimate(luma)
     q = quality(a64)
-    b = dct16(a64)
+    b = dct16(a64, fma)
     med = np.sort(b.ravel())[127]  # Torben on 256 values returns the 128th smallest
     bits = (b.ravel() > med).astype(np.uint8)
     return np.packbits(bits, bitorder="little").tobytes(), q, b
 
 
-def hash_gray(frame: np.ndarray):
-    return hash_from_luma(luma_gray(frame))
+def hash_gray(frame: np.ndarray, fma: bool = False):
+    return hash_from_luma(luma_gray(frame), fma)
 
 
-def hash_rgb(frame: np.ndarray):
-    return hash_from_luma(luma_rgb(frame))
+def hash_rgb(frame: np.ndarray, fma: bool = False):
+    return hash_from_luma(luma_rgb(frame), fma)
 
 
 def hamming(a: bytes, b: bytes) -> int:

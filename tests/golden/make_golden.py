@@ -24,9 +24,9 @@ from oracle import pdq_numpy as P  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
-def check_frames(frames, hashes, quality, coeffs):
+def check_frames(frames, hashes, quality, coeffs, fma=False):
     for f in range(len(frames)):
-        h, q, b = (P.hash_rgb if frames.ndim == 4 else P.hash_gray)(frames[f])
+        h, q, b = (P.hash_rgb if frames.ndim == 4 else P.hash_gray)(frames[f], fma)
         assert h == hashes[f].tobytes(), f"hash mismatch frame {f}"
         assert q == quality[f], f"quality mismatch frame {f}"
         assert np.array_equal(b.ravel().view(np.uint32), coeffs[f].view(np.uint32)), f"coeff mismatch frame {f}"
@@ -47,13 +47,21 @@ def main():
     fr = np.concatenate([fr, edge])
     h, q, c = O.hash_frames(fr, want_coeffs=True)
     check_frames(fr, h, q, c)
-    np.savez_compressed(os.path.join(OUT, "pdq_gray64.npz"), frames=fr, hashes=h, quality=q, coeffs=c)
+    # the opt-in "fma" DCT mode (upstream's arm64 numerics), verified the same way
+    hf, qf, cf = O.hash_frames(fr, want_coeffs=True, fma=True)
+    check_frames(fr, hf, qf, cf, fma=True)
+    assert np.array_equal(q, qf)
+    np.savez_compressed(os.path.join(OUT, "pdq_gray64.npz"), frames=fr, hashes=h, quality=q, coeffs=c,
+                        hashes_fma=hf, coeffs_fma=cf)
 
     # 2) rgb24 frames that need the Jarosz down-sampler: the reference's 512x512 plus odd sizes
     rgb512 = synth.frames_rgb(2, seed=102, h=512, w=512)
     h5, q5, c5 = O.hash_frames(rgb512, want_coeffs=True)
     check_frames(rgb512, h5, q5, c5)
-    np.savez_compressed(os.path.join(OUT, "pdq_rgb512.npz"), frames=rgb512, hashes=h5, quality=q5, coeffs=c5)
+    h5f, q5f, c5f = O.hash_frames(rgb512, want_coeffs=True, fma=True)
+    check_frames(rgb512, h5f, q5f, c5f, fma=True)
+    np.savez_compressed(os.path.join(OUT, "pdq_rgb512.npz"), frames=rgb512, hashes=h5, quality=q5, coeffs=c5,
+                        hashes_fma=h5f, coeffs_fma=c5f)
     rgbodd = synth.frames_rgb(3, seed=103, h=100, w=333)
     ho, qo, co = O.hash_frames(rgbodd, want_coeffs=True)
     check_frames(rgbodd, ho, qo, co)

@@ -57,6 +57,60 @@ def test_k1_gray64_extreme_frames(gpu, hvd, oracle):
     assert np.array_equal(q, qo) and np.array_equal(h, ho)
 
 
+@pytest.fixture
+def fma_mode(hvd):
+    hvd.vpdq.set_dct_mode("fma")
+    try:
+        yield
+    finally:
+        hvd.vpdq.set_dct_mode("strict")
+
+
+def test_k1_fma_mode_golden(gpu, hvd, fma_mode):
+    """Opt-in DCT mode on the matrix cores (v_mfma_f32_16x16x4_f32 = an fmaf chain): bit-exact against
+    the frozen fma-mode vectors, 64x64 and through the down-sampler."""
+    assert hvd.vpdq.get_dct_mode() == "fma"
+    g = load_golden("pdq_gray64.npz")
+    h, q = hvd.vpdq.hash_frames(g["frames"])
+    assert np.array_equal(q, g["quality"])
+    assert np.array_equal(h, g["hashes_fma"]), f"{int((h != g['hashes_fma']).any(1).sum())} hash mismatches"
+    r = load_golden("pdq_rgb512.npz")
+    h, q = hvd.vpdq.hash_frames(r["frames"])
+    assert np.array_equal(h, r["hashes_fma"]) and np.array_equal(q, r["quality"])
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 10000])
+def test_k1_fma_mode_vs_oracle(gpu, hvd, oracle, fma_mode, n):
+    fr = hvd.synth.frames_gray(n, seed=21)
+    h, q = hvd.vpdq.hash_frames(fr)
+    ho, qo = oracle.hash_frames(fr, num_threads=8, fma=True)
+    assert np.array_equal(q, qo)
+    assert np.array_equal(h, ho), f"{int((h != ho).any(1).sum())} hash mismatches"
+    rgb = hvd.synth.frames_rgb(min(n, 40), seed=22, h=64, w=64)
+    h, q = hvd.vpdq.hash_frames(rgb)
+    ho, qo = oracle.hash_frames(rgb, fma=True)
+    assert np.array_equal(h, ho) and np.array_equal(q, qo)
+
+
+def test_k1_dct_mode_default_is_strict_and_modes_stay_close(gpu, hvd, oracle):
+    assert hvd.vpdq.get_dct_mode() == "strict"
+    with pytest.raises(ValueError):
+        hvd.vpdq.set_dct_mode("fast")
+    assert hvd._lib.load().hvd_set_pdq_dct_mode(7) == -1
+    fr = hvd.synth.frames_gray(2000, seed=23)
+    hs, qs = hvd.vpdq.hash_frames(fr)
+    hvd.vpdq.set_dct_mode("fma")
+    try:
+        hf, qf = hvd.vpdq.hash_frames(fr)
+    finally:
+        hvd.vpdq.set_dct_mode("strict")
+    h2, _ = hvd.vpdq.hash_frames(fr)
+    assert np.array_equal(h2, hs) and np.array_equal(qs, qf)
+    good = qs >= 31                                     # frames the reference keeps (DedupeDB.py:535-559)
+    d = np.unpackbits(hs[good] ^ hf[good], axis=1).sum(1)
+    assert d.max() <= 31, "a mode flip alone must never break a frame match at the default tolerance"
+
+
 def test_k1_empty_batch(gpu, hvd):
     h, q = hvd.vpdq.hash_frames(np.zeros((0, 64, 64), np.uint8))
     assert h.shape == (0, 32) and q.shape == (0,)

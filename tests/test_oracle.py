@@ -43,6 +43,46 @@ def test_golden_rgb512(oracle):
     assert hh == g["hashes"][0].tobytes() and qq == g["quality"][0]
 
 
+def test_golden_fma_mode_both_restatements(oracle):
+    """The opt-in fused-multiply-add DCT mode: C oracle (libm fmaf) and numpy (TwoSum, no libm) agree
+    with the frozen vectors; the quality and the default mode are untouched by it."""
+    g = load_golden("pdq_gray64.npz")
+    h, q, c = oracle.hash_frames(g["frames"], want_coeffs=True, fma=True)
+    assert np.array_equal(h, g["hashes_fma"]) and np.array_equal(q, g["quality"])
+    assert np.array_equal(c.view(np.uint32), g["coeffs_fma"].view(np.uint32))
+    assert not np.array_equal(g["coeffs_fma"].view(np.uint32), g["coeffs"].view(np.uint32))
+    for f in range(1, len(g["frames"]), 5):
+        hh, qq, b = P.hash_gray(g["frames"][f], fma=True)
+        assert hh == g["hashes_fma"][f].tobytes() and qq == g["quality"][f]
+        assert np.array_equal(b.ravel().view(np.uint32), g["coeffs_fma"][f].view(np.uint32))
+    h0, _ = oracle.hash_frames(g["frames"])  # the mode does not leak into later calls
+    assert np.array_equal(h0, g["hashes"])
+    r = load_golden("pdq_rgb512.npz")
+    h, q = oracle.hash_frames(r["frames"], fma=True)
+    assert np.array_equal(h, r["hashes_fma"]) and np.array_equal(q, r["quality"])
+
+
+def test_fma32_helper_is_a_single_rounding():
+    """_fma32 against exact rational arithmetic, including products that land on float32 ties."""
+    from fractions import Fraction
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(4000).astype(np.float32)
+    b = rng.standard_normal(4000).astype(np.float32)
+    c = (rng.standard_normal(4000) * 10.0 ** rng.integers(-6, 3, 4000)).astype(np.float32)
+    # engineered ties: a*b = 1 + 2^-24 exactly half an ulp above 1, then c decides the direction
+    a[:4] = np.float32(1 + 2.0 ** -12); b[:4] = np.float32(1 - 2.0 ** -12 + 2.0 ** -24)
+    c[:4] = np.float32([0.0, 2.0 ** -60, -2.0 ** -60, 2.0 ** -30])
+    got = P._fma32(a, b, c)
+    for i in range(len(a)):
+        exact = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        r = np.float32(float(got[i]))
+        lo, hi = np.nextafter(r, np.float32(-np.inf)), np.nextafter(r, np.float32(np.inf))
+        err = abs(Fraction(float(r)) - exact)
+        assert err <= abs(Fraction(float(lo)) - exact) and err <= abs(Fraction(float(hi)) - exact), i
+        if err == abs(Fraction(float(lo)) - exact) or err == abs(Fraction(float(hi)) - exact):
+            assert (int(r.view(np.uint32)) & 1) == 0, f"tie not broken to even at {i}"
+
+
 def test_golden_rgb_misc(oracle):
     g = load_golden("pdq_rgb_misc.npz")
     h, q = oracle.hash_frames(g["frames_odd"])
