@@ -157,6 +157,29 @@ def hash_from_luma(luma: np.ndarray, fma: bool = False) -> tuple[bytes, int, np.
     return np.packbits(bits, bitorder="little").tobytes(), q, b
 
 
+def hash_gray64_batch(frames: np.ndarray, fma: bool = False):
+    """uint8[n,64,64] -> (hashes u8[n,32], quality i32[n], coeffs f32[n,256]); the same arithmetic as
+    hash_gray, vectorised over the frame axis so that 10^4 frames take seconds."""
+    a = luma_gray(frames)                                                # [n,64,64]
+    dv = ((a[:, :-1, :] - a[:, 1:, :]) * F(100.0)) / F(255.0)
+    dh = ((a[:, :, :-1] - a[:, :, 1:]) * F(100.0)) / F(255.0)
+    g = np.abs(np.trunc(dv).astype(np.int64)).sum((1, 2)) + np.abs(np.trunc(dh).astype(np.int64)).sum((1, 2))
+    q = np.minimum(g // 90, 100).astype(np.int32)
+    n = len(frames)
+    t = np.zeros((n, 16, 64), dtype=np.float32)
+    for k in range(64):
+        dk, ak = _D[None, :, k : k + 1], a[:, k : k + 1, :]
+        t = _fma32(np.broadcast_to(dk, t.shape), np.broadcast_to(ak, t.shape), t) if fma else t + dk * ak
+    b = np.zeros((n, 16, 16), dtype=np.float32)
+    for k in range(64):
+        tk, dk = t[:, :, k : k + 1], _D[None, None, :, k]
+        b = _fma32(np.broadcast_to(tk, b.shape), np.broadcast_to(dk, b.shape), b) if fma else b + tk * dk
+    b = b.reshape(n, 256)
+    med = np.sort(b, axis=1)[:, 127:128]
+    bits = (b > med).astype(np.uint8)
+    return np.packbits(bits, axis=1, bitorder="little"), q, b
+
+
 def hash_gray(frame: np.ndarray, fma: bool = False):
     return hash_from_luma(luma_gray(frame), fma)
 

@@ -83,6 +83,36 @@ def test_fma32_helper_is_a_single_rounding():
             assert (int(r.view(np.uint32)) & 1) == 0, f"tie not broken to even at {i}"
 
 
+@pytest.mark.parametrize("fma,n", [(False, 10000), (True, 3000)])
+def test_two_restatements_agree_on_many_frames(oracle, fma, n):
+    """C oracle vs the independent numpy restatement, bit for bit (hash, quality and all
+    256 coefficients) on 10^4 seeded frames of the bench generator."""
+    import hvd_amd
+    fr = hvd_amd.synth.frames_gray(n, seed=2)
+    h, q, c = oracle.hash_frames(fr, num_threads=8, want_coeffs=True, fma=fma)
+    for lo in range(0, n, 2500):
+        hp, qp, cp = P.hash_gray64_batch(fr[lo:lo + 2500], fma=fma)
+        sl = slice(lo, lo + 2500)
+        assert np.array_equal(cp.view(np.uint32), c[sl].view(np.uint32))
+        assert np.array_equal(qp, q[sl]) and np.array_equal(hp, h[sl])
+
+
+def test_mirrored_frame_flips_the_sign_of_even_indexed_frequencies(oracle):
+    """Analytic property of the DCT rows: D[i][63-j] = (-1)^(i+1) ... with frequency index
+    i+1, so mirroring a frame left-right negates coefficient columns 0,2,4,.. and keeps 1,3,5,..; mirroring
+    top-bottom does the same to coefficient rows. Float summation order differs, hence a tolerance."""
+    import hvd_amd
+    fr = hvd_amd.synth.frames_gray(16, seed=77)
+    _, _, c = oracle.hash_frames(fr, want_coeffs=True)
+    _, _, ch = oracle.hash_frames(fr[:, :, ::-1], want_coeffs=True)
+    _, _, cv = oracle.hash_frames(fr[:, ::-1, :], want_coeffs=True)
+    c, ch, cv = (x.reshape(-1, 16, 16).astype(np.float64) for x in (c, ch, cv))
+    sgn = np.where(np.arange(16) % 2 == 0, -1.0, 1.0)
+    assert np.allclose(ch, c * sgn[None, None, :], atol=2e-2)
+    assert np.allclose(cv, c * sgn[None, :, None], atol=2e-2)
+    assert np.abs(c).max() > 50  # the tolerance is tiny against the signal
+
+
 def test_golden_rgb_misc(oracle):
     g = load_golden("pdq_rgb_misc.npz")
     h, q = oracle.hash_frames(g["frames_odd"])
