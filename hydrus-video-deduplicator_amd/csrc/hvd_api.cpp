@@ -286,6 +286,16 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_mfma_col_chunk_max = (uint32_t)value;
         return HVD_OK;
     }
+    if (strcmp(key, "pdq_down512_wave") == 0) {
+        if (value < 0 || value > 2) return fail(HVD_ERR_ARG, "pdq_down512_wave: 0 never, 1 by batch size, 2 always");
+        hvd::g_pdq_down512_wave = value;
+        return HVD_OK;
+    }
+    if (strcmp(key, "pdq_down512_wave_grid") == 0) {
+        if (value < 0) return fail(HVD_ERR_ARG, "pdq_down512_wave_grid must not be negative (0 = default)");
+        hvd::g_pdq_down512_wave_grid = value;
+        return HVD_OK;
+    }
     if (strcmp(key, "pdq_down512_strip64") == 0) {
         hvd::g_pdq_down512_strip64 = value != 0;
         return HVD_OK;

@@ -1085,6 +1085,413 @@ __global__ __launch_bounds__(kNW * 64) void k_down512s(const uint8_t* __restrict
 #undef HVD_RUN_CHUNK
 #undef HVD_RUN_STEP
 
+// ---------------------------------------------------------------------------
+// k_down512w: the same fused down-sampler with ONE WAVE PER FRAME.
+//
+// k_down512 spends most of its time with one half-filled wave walking a 512-row strip (pass B)
+// while the workgroup's other seven waves wait at a barrier. Here a lone wave owns a frame and
+// walks it in tile rows of 64 rows and steps of 32 columns; no wave ever waits for another and the
+// only synchronisation is the wave's own LDS ordering. A lone wave issues a dependent VALU
+// instruction only every ~8.5 clocks (profiles/r01_ubench_latency.txt), so throughput comes from
+// waves per SIMD, i.e. from a small LDS footprint: the transposition buffer is 64 rows x 32 columns
+// (8.4 KB => 4 waves per SIMD), and the lanes still all work in every pass because the upper half
+// of the wave runs ONE STEP BEHIND the lower half:
+//   step tx of tile row ty:  lanes 0..31  <-> rows 64ty+0..31  of column tile tx
+//                            lanes 32..63 <-> rows 64ty+32..63 of column tile tx-1
+//   A  lane = row     luma of the lane's 32 pixels, rep-1 filter along the row (state in registers
+//                     from step to step); output c lands in buf[row][c] <-> column 32t-2+c (lag 2)
+//   B  lane = (half, column c)   rep-1 filter down the 32 buffer rows of the lane's half, in place
+//                     (buffer row r <-> row 64ty-2+r). The upper half continues the column that the
+//                     lower half walked one step earlier (state handed over by a 32-lane shuffle);
+//                     across tile rows the state goes through a small per-wave global scratch.
+//   C  lane = row     rep-2 filter along the row; only the 4 decimation samples per row and step are
+//                     kept, in the per-wave sample ring cs[slot & 31][row] (global, coalesced, L2-resident)
+//   D  lane = sample column j, 16 columns every fourth step: the samples come back through the idle
+//                     buffer, rep-2 filter down the 64 rows, emits out64[i][j] at the 8 sampled rows
+// Column tile 16 and tile row 8 are the tails of box1DFloat's phase 4 (one column / one row of each is
+// needed by the decimation). Starting a line is the steady step on an all-zero state (0 + x and
+// x - 0 are exact), so only the two /3 outputs per line are special.
+// Scaling: upstream multiplies every window sum by 0.25 before the next pass. Multiplying by a power
+// of two is exact and commutes with every later rounding (no overflow/underflow here: values are 0 or
+// in [0.114, 255*256]), so the passes hand on the unscaled sums and the product 1/256 is applied once,
+// in D; the /3 edge outputs are multiplied by 4 to sit on the same scale. Bit-identical to k_down512,
+// the generic path and the oracle.
+constexpr int kWR = 64;                                 // rows per tile row (= lanes)
+constexpr int kWT = 32;                                 // columns per step
+constexpr int kWNX = kF / kWT;                          // full column tiles (16); index 16 = tail
+constexpr int kWNY = kF / kWR;                          // full tile rows (8); index 8 = tail
+constexpr int kWC = 16;                                 // elements per register chunk of a pass
+constexpr int kWStateFloats = (kWNX + 1) * 5 * 32;      // pass-B state: [column tile][5][column]
+constexpr int kWScratchFloats = kWStateFloats + 32 * 64;  // + the ring of C samples: [slot & 31][row]
+
+__device__ __forceinline__ void wave_mem_sync() {  // stores of this wave become visible to its other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One chunk of upstream's running sum (window 4): step r adds x[r] and drops the input four steps
+// back, which is x[r-4] inside the chunk and lag[r] (the previous chunk's last four inputs) before.
+// o[r] is the sum after step r = 4x the filter output two positions behind the input.
+template <int N>
+__device__ __forceinline__ void w_run(float& sum, float (&lag)[4], const float (&x)[N], float (&o)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        sum = __fsub_rn(__fadd_rn(sum, x[r]), r < 4 ? lag[r] : x[r - 4]);
+        o[r] = sum;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lag[k] = x[N - 4 + k];
+}
+
+// Global -> register -> LDS staging of the frame bytes. A lane of pass A needs the contiguous bytes of
+// ITS row, so a direct load would touch 64 different cache lines per instruction (the TCP then stalls on
+// outstanding misses). Instead the wave reads a UNIT = 32 rows (one half of the wave) x two steps
+// (64 pixels: 192 bytes rgb, a whole number of 64-byte DRAM sectors, so nothing is fetched twice) as
+// consecutive 16-byte pieces (5.3 rows per instruction), parks it in LDS with a padded row stride
+// (conflict-free 128-bit reads), and every lane of that half picks up its row. The bytes of the unit's first
+// step land in a staging area that aliases the transposition buffer (they are consumed at once); the bytes
+// of its second step are parked in 3.5 KB of LDS of their own until the next step. The halves refill on
+// alternate steps, so one parking area serves both.
+template <int CH>
+struct TileLoad {
+    static constexpr int SQ = kWT * CH / 16;          // 16-byte pieces per row and step (6 rgb, 2 gray)
+    static constexpr int PPR = 2 * SQ;                // pieces per row of a unit
+    static constexpr int NI = 32 * PPR / 64;          // load instructions per unit (6 / 2)
+    static constexpr int RS = kWT * CH + 16;          // staged row stride in bytes, one step's bytes per row (112 / 48)
+};
+
+// Buffer addressing (SGPR resource + 32-bit lane offset + SGPR offset): one VGPR per lane offset instead
+// of a 64-bit address pair per access, and out-of-range lanes read 0 / store nothing.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t idx) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(idx * 4u), 0, 0));
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t idx, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(idx * 4u), 0, 0);
+}
+
+// soff: wave-uniform byte offset of the unit inside the frame. Instruction i = (NI/2) g + sub covers rows
+// 16 g .. 16 g + 15 (piece u = 64 sub + lane of that 16-row group), so only NI/2 lane-dependent offsets exist;
+// the group offset rides in the scalar offset (loads) or the immediate offset (LDS).
+// cache policy of the frame loads
+constexpr int kFrameLoadAux = 0;  // cache-policy bits (1 = sc0, 2 = nt, 16 = sc1); nt was measured slower (it also defeats the L2 reuse of shared sectors)
+template <int CH>
+__device__ __forceinline__ void unit_fetch(__amdgpu_buffer_rsrc_t frame, const uint32_t soff, const int lane,
+                                           uint4 (&p)[TileLoad<CH>::NI]) {
+    constexpr int PPR = TileLoad<CH>::PPR, SUB = TileLoad<CH>::NI / 2;
+    static_assert(16 * PPR == 64 * SUB, "16 rows are a whole number of instructions");
+#pragma unroll
+    for (int sub = 0; sub < SUB; ++sub) {
+        const uint32_t u = 64u * sub + (uint32_t)lane;
+        const uint32_t off = (u / PPR) * (uint32_t)(kF * CH) + (u % PPR) * 16u;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(frame, (int)off, (int)(soff + g * 16 * (kF * CH)), kFrameLoadAux);
+            p[SUB * g + sub] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
+// first-step pieces of every row -> stage, second-step pieces -> park (both LDS, same row stride)
+template <int CH>
+__device__ __forceinline__ void unit_stage(uint8_t* stage, uint8_t* park, const int lane, const uint4 (&p)[TileLoad<CH>::NI]) {
+    constexpr int PPR = TileLoad<CH>::PPR, SUB = TileLoad<CH>::NI / 2, SQ = TileLoad<CH>::SQ;
+#pragma unroll
+    for (int sub = 0; sub < SUB; ++sub) {
+        const uint32_t u = 64u * sub + (uint32_t)lane;
+        const uint32_t pp = u % PPR;
+        uint8_t* dst = (pp < SQ ? stage : park) + (u / PPR) * TileLoad<CH>::RS + (pp < SQ ? pp : pp - SQ) * 16u;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) *reinterpret_cast<uint4*>(dst + g * 16 * TileLoad<CH>::RS) = p[SUB * g + sub];
+    }
+}
+
+template <int N>
+__device__ __forceinline__ uint32_t fifo_word(const uint4 (&f)[N], const int k) {  // k is a compile-time constant after unrolling
+    const uint4 q = f[k >> 2];
+    return (k & 3) == 0 ? q.x : (k & 3) == 1 ? q.y : (k & 3) == 2 ? q.z : q.w;
+}
+__device__ __forceinline__ float luma_rgb_f(const float r, const float g, const float b) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(0.299f, r), __fmul_rn(0.587f, g)), __fmul_rn(0.114f, b));
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 : 4))) void k_down512w(
+    const uint8_t* __restrict__ frames, long long n, float* __restrict__ out64, float* __restrict__ wscratch) {
+    constexpr int NCH = kWT / kWC;      // register chunks per pass (2)
+    constexpr int QPC = kWC * CH / 16;  // 16-byte pieces per chunk of a row
+    constexpr int LD = kWT + 1;
+    __shared__ __attribute__((aligned(16))) float buf[kWR][LD];
+    static_assert(sizeof(buf) >= 32 * TileLoad<CH>::RS, "the byte staging aliases the transposition buffer");
+    __shared__ __attribute__((aligned(16))) uint8_t park[32 * TileLoad<CH>::RS];
+    constexpr int SQ = TileLoad<CH>::SQ;
+    static_assert(SQ == NCH * QPC, "a step is NCH chunks of QPC pieces");
+    uint8_t* stage = reinterpret_cast<uint8_t*>(&buf[0][0]);
+    const int lane = threadIdx.x;
+    const int half = lane >> 5, cl5 = lane & 31;
+    // per-wave scratch: pass-B state [17][5][32], then the ring of C samples [32 slots][64 rows]
+    const __amdgpu_buffer_rsrc_t rs =
+        make_rsrc(wscratch + (size_t)blockIdx.x * kWScratchFloats, kWScratchFloats * sizeof(float));
+    constexpr uint32_t kCs = kWStateFloats;
+    constexpr uint32_t row_bytes = kF * CH, frame_bytes = kF * kF * CH;
+
+    // two prefetch buffers: pre[0] always holds the lower half's next unit, pre[1] the upper half's; each is
+    // refilled right after it was staged, i.e. TWO steps before it is needed (HBM latency under load exceeds
+    // one step; profiles/r01_down512w_ablation.txt)
+    uint4 pre[2][TileLoad<CH>::NI];
+#pragma unroll
+    for (int i = 0; i < TileLoad<CH>::NI; ++i) pre[0][i] = pre[1][i] = make_uint4(0, 0, 0, 0);
+    if ((long long)blockIdx.x < n) {
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(frames + (size_t)blockIdx.x * frame_bytes, frame_bytes);
+        unit_fetch<CH>(r0, 0, lane, pre[0]);
+        unit_fetch<CH>(r0, 32 * row_bytes, lane, pre[1]);
+    }
+    uint4 fifo[SQ];  // the bytes of this lane's row for this step
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) fifo[q] = make_uint4(0, 0, 0, 0);
+
+    for (long long f = blockIdx.x; f < n; f += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rf = make_rsrc(frames + (size_t)f * frame_bytes, frame_bytes);
+        const __amdgpu_buffer_rsrc_t rd = make_rsrc(out64 + (size_t)f * 4096, 4096 * sizeof(float));
+        float sD = 0.0f, dl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+#pragma unroll 1
+        for (int ty = 0; ty <= kWNY; ++ty) {
+            float sA = 0.0f, al[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float sC = 0.0f, cl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            // pass-B state a lane starts its step with: the upper half gets it from the lower half's previous step (a
+            // 32-lane shuffle at the end of B), the lower half from the tile row above (loaded at the top of the step)
+            float inB = 0.0f, inl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float nxB = 0.0f, nxl[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the lower half's state for the NEXT step, in flight
+            if (ty > 0 && half == 0) {  // column tile 0 of this tile row
+                nxB = buf_ld(rs, (uint32_t)cl5);
+                nxl[0] = buf_ld(rs, 32u + cl5); nxl[1] = buf_ld(rs, 64u + cl5);
+                nxl[2] = buf_ld(rs, 96u + cl5); nxl[3] = buf_ld(rs, 128u + cl5);
+            }
+            const uint32_t rbase = (uint32_t)(kWR * ty) * row_bytes;  // byte offset of the tile row in the frame
+
+            // ---------------- D: rep-2 down 16 sample columns at a time (lane = j) ----------------------------
+            // After step 4c+5 both halves are through slots <= 16c+19, so slots 16c+1 .. 16c+16 <-> sample columns
+            // j = 16c .. 16c+15 <-> lanes 16c .. 16c+15 can run (each lane owns one column for the whole frame: its
+            // running sum lives in the same registers from tile row to tile row). It runs at the TOP of step 4c+6,
+            // before that step's frame fetch is issued: vmcnt retires in order, so waiting for these loads any later
+            // would also wait for a fetch that has only just left. Consuming the samples this soon keeps the ring small
+            // (8 KB per wave, L2-resident). The samples come back row-per-lane (coalesced) and turn through the idle
+            // buffer: buf[row][slot]. Row r <-> input row Y = 64ty-2+r; output Y-2 is decimation row i = 8ty-1+r/8
+            // iff r % 8 == 0.
+            auto pass_d = [&](const int c16) {
+                    float t[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    t[e] = buf_ld(rs, kCs + (uint32_t)(((16 * c16 + 1 + e) & 31) * 64 + lane));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) buf[lane][e] = t[e];
+                wave_mem_sync();
+                const int jl = lane - 16 * c16;
+                if (jl >= 0 && jl < 16) {
+                    if (ty < kWNY) {
+#pragma unroll
+                        for (int k = 0; k < kWR / kWC; ++k) {
+                            float zz[kWC], o[kWC];
+#pragma unroll
+                            for (int r = 0; r < kWC; ++r) zz[r] = buf[kWC * k + r][jl];
+                            if (k == 0 && ty == 0) zz[0] = zz[1] = 0.0f;  // the line's inputs start at row 2
+                            w_run<kWC>(sD, dl, zz, o);
+                            if (k > 0 || ty > 0) buf_st(rd, (uint32_t)((8 * ty - 1 + 2 * k) * 64 + lane), __fmul_rn(o[0], 0x1p-8f));
+                            buf_st(rd, (uint32_t)((8 * ty + 2 * k) * 64 + lane), __fmul_rn(o[8], 0x1p-8f));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {  // Y = 510 (row 0 of the tail tile row): output 508 = decimation row 63
+                        sD = __fsub_rn(__fadd_rn(sD, buf[0][jl]), dl[0]);
+                        buf_st(rd, (uint32_t)(63 * 64 + lane), __fmul_rn(sD, 0x1p-8f));
+                    }
+                }
+                wave_mem_sync();  // buf is rewritten by the next step
+            };
+
+#pragma unroll 1
+            for (int tp = 0; tp <= kWNX + 1; tp += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {  // even / odd step: static after unrolling (prefetch buffer, refilling half)
+                const int tx = tp + par;
+                const int txl = tx - half;  // the column tile this lane works on in this step
+                if (par == 0 && (tx & 3) == 2 && tx >= 6) pass_d((tx - 6) >> 2);
+                // pass-B state of the lower half for this step: left by the upper half one tile row up; the
+                // load is issued here so that its latency hides behind pass A
+                // (vmcnt retires in order: a wait for these small loads also waits for every load issued before
+                // them, so they are issued one step AHEAD of their use and BEFORE this step's frame fetch -- otherwise
+                // they would cut the fetch's two steps of flight time down to a fraction of one)
+                if (half == 0) {
+                    inB = nxB;
+                    inl[0] = nxl[0]; inl[1] = nxl[1]; inl[2] = nxl[2]; inl[3] = nxl[3];
+                    nxB = 0.0f;
+                    nxl[0] = nxl[1] = nxl[2] = nxl[3] = 0.0f;
+                    if (ty > 0 && tx + 1 <= kWNX) {
+                        const uint32_t pi = (uint32_t)(tx + 1) * (5 * 32) + (uint32_t)cl5;
+                        nxB = buf_ld(rs, pi);
+                        nxl[0] = buf_ld(rs, pi + 32); nxl[1] = buf_ld(rs, pi + 64);
+                        nxl[2] = buf_ld(rs, pi + 96); nxl[3] = buf_ld(rs, pi + 128);
+                    }
+                }
+                // ---------------- A: luma + rep-1 along the row (lane = row 64ty + lane) -----------------
+                if (ty < kWNY) {
+                    float tailA = 0.0f;
+                    if (tx >= kWNX) {  // phase 4: output 510 = (sum - x[508]) / 3; output 511 is never sampled
+                        tailA = __fmul_rn(__fdiv_rn(__fsub_rn(sA, al[0]), 3.0f), 4.0f);
+                    }
+                    if (tx <= kWNX) {
+                        // unit m of half `par` arrives in this step (lower half: steps 2m, 2m+1 <-> tiles 2m, 2m+1;
+                        // upper half: steps 2m+1, 2m+2); the other half moves on to the second step of its unit
+                        const int hr = par;
+                        if (half != hr) {  // second step of this half's unit: parked one step ago
+#pragma unroll
+                            for (int q = 0; q < SQ; ++q)
+                                fifo[q] = *reinterpret_cast<const uint4*>(park + cl5 * TileLoad<CH>::RS + q * 16);
+                        }
+                        wave_mem_sync();  // ... before the arriving unit is parked there
+                        if (tx < kWNX) {
+                            unit_stage<CH>(stage, park, lane, pre[par]);
+                            // this half's next unit (needed two steps from now, or in the next tile row / frame)
+                            if (tx + 2 < kWNX) {
+                                unit_fetch<CH>(rf, rbase + (uint32_t)(32 * par) * row_bytes + (uint32_t)((tx + 2 - par) >> 1) * (2 * kWT * CH),
+                                               lane, pre[par]);
+                            } else if (ty + 1 < kWNY) {
+                                unit_fetch<CH>(rf, rbase + (uint32_t)(kWR + 32 * par) * row_bytes, lane, pre[par]);
+                            } else if (f + gridDim.x < n) {
+                                unit_fetch<CH>(make_rsrc(frames + (size_t)(f + gridDim.x) * frame_bytes, frame_bytes),
+                                               (uint32_t)(32 * par) * row_bytes, lane, pre[par]);
+                            }
+                            wave_mem_sync();
+                            if (half == hr) {
+#pragma unroll
+                                for (int q = 0; q < SQ; ++q)
+                                    fifo[q] = *reinterpret_cast<const uint4*>(stage + cl5 * TileLoad<CH>::RS + q * 16);
+                            }
+                            wave_mem_sync();  // the staged bytes are in registers before A overwrites them
+                        }
+                        if (tx <= 1 && txl == 0) {  // a new line starts from the all-zero state
+                            sA = 0.0f;
+                            al[0] = al[1] = al[2] = al[3] = 0.0f;
+                        }
+                        // 4 pixels at a time (12 bytes rgb / 4 bytes gray), straight from the FIFO words: few live
+                        // registers, and the scheduler may overlap the luma of one group with the running sum of the
+                        // previous one (the fence every two groups keeps it from unrolling the whole step into registers)
+#pragma unroll
+                        for (int j = 0; j < kWT / 4; ++j) {
+                            float v[4];
+                            if (CH == 3) {
+                                const uint32_t w0 = fifo_word(fifo, 3 * j), w1 = fifo_word(fifo, 3 * j + 1), w2 = fifo_word(fifo, 3 * j + 2);
+                                v[0] = luma_rgb_f((float)(w0 & 0xFFu), (float)((w0 >> 8) & 0xFFu), (float)((w0 >> 16) & 0xFFu));
+                                v[1] = luma_rgb_f((float)(w0 >> 24), (float)(w1 & 0xFFu), (float)((w1 >> 8) & 0xFFu));
+                                v[2] = luma_rgb_f((float)((w1 >> 16) & 0xFFu), (float)(w1 >> 24), (float)(w2 & 0xFFu));
+                                v[3] = luma_rgb_f((float)((w2 >> 8) & 0xFFu), (float)((w2 >> 16) & 0xFFu), (float)(w2 >> 24));
+                            } else {
+                                const uint32_t w0 = fifo_word(fifo, j);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = luma_gray((w0 >> (8 * k)) & 0xFFu);
+                            }
+                            float o[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                sA = __fsub_rn(__fadd_rn(sA, v[k]), al[k]);
+                                o[k] = sA;
+                                al[k] = v[k];
+                            }
+                            if (j == 0 && tx <= 1) {  // output 0 of the line = (x0 + x1 + x2) / 3
+                                if (txl == 0) o[2] = __fmul_rn(__fdiv_rn(o[2], 3.0f), 4.0f);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) buf[lane][4 * j + k] = o[k];
+                            if (j & 1) __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (tx >= kWNX && txl == kWNX) buf[lane][0] = tailA;
+                }
+                wave_mem_sync();
+
+                // ---------------- B: rep-1 down the buffer columns, in place (lane = half, column) --------
+                {
+                    const bool valid = (txl == 0) ? (cl5 >= 2) : (txl == kWNX) ? (cl5 == 0) : (txl > 0 && txl < kWNX);
+                    const uint32_t sti = (uint32_t)(txl < 0 ? 0 : txl) * (5 * 32) + (uint32_t)cl5;  // index into the state scratch
+                    if (ty < kWNY) {
+                        float sB = inB, bl[4] = {inl[0], inl[1], inl[2], inl[3]};
+                        float* bp = &buf[32 * half][cl5];
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) {
+                            float x[kWC], o[kWC];
+#pragma unroll
+                            for (int r = 0; r < kWC; ++r) x[r] = bp[(kWC * k + r) * LD];
+                            w_run<kWC>(sB, bl, x, o);
+                            if (k == 0 && ty == 0) {  // output row 0 = (x0 + x1 + x2) / 3, lower half only
+                                if (half == 0) o[2] = __fmul_rn(__fdiv_rn(o[2], 3.0f), 4.0f);
+                            }
+#pragma unroll
+                            for (int r = 0; r < kWC; ++r) bp[(kWC * k + r) * LD] = o[r];
+                            __builtin_amdgcn_sched_barrier(0);  // one chunk of rows in registers at a time
+                        }
+                        if (half && valid) {
+                            buf_st(rs, sti, sB);
+                            buf_st(rs, sti + 32, bl[0]); buf_st(rs, sti + 64, bl[1]);
+                            buf_st(rs, sti + 96, bl[2]); buf_st(rs, sti + 128, bl[3]);
+                        }
+                        // lower half -> upper half of the next step (lane l -> lane l + 32)
+                        inB = __shfl_up(sB, 32, 64);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) inl[k] = __shfl_up(bl[k], 32, 64);
+                    } else if (half == 0 && valid) {  // phase 4, row 510 only (buffer row 0)
+                        const float sB = __fsub_rn(inB, inl[0]);
+                        buf[0][cl5] = __fmul_rn(__fdiv_rn(sB, 3.0f), 4.0f);
+                    }
+                }
+                wave_mem_sync();
+
+                // ---------------- C: rep-2 along the row over the buffer columns (lane = buffer row) -------
+                // buffer column c <-> input index X = 32t-2+c; output X-2 is decimation sample j = 4t-1+c/8 iff c
+                // is a multiple of 8 -> sample slot 4t + c/8 (slot 0 = j -1 does not exist). The samples go to
+                // the per-wave ring cs[slot & 31][row] in global memory (one 256-byte row per slot: coalesced).
+                // Lanes whose row does not exist (ty = 0: r < 2; ty = 8: r > 0) compute on leftovers; D ignores them.
+                {
+                    const uint32_t slot0 = (uint32_t)(txl < 0 ? 0 : txl) * 4u;
+                    if (tx >= kWNX && txl == kWNX) {  // X = 510: output 508 = sample column 63 (slot 64)
+                        buf_st(rs, kCs + (slot0 & 31u) * 64u + (uint32_t)lane, __fsub_rn(__fadd_rn(sC, buf[lane][0]), cl[0]));
+                    }
+                    if (tx <= kWNX) {
+                        const bool first = (tx <= 1) && (txl == 0);
+                        if (first) {
+                            sC = 0.0f;
+                            cl[0] = cl[1] = cl[2] = cl[3] = 0.0f;
+                        }
+                        const bool store = (txl >= 0) && (txl < kWNX);
+                        const uint32_t csi = kCs + (slot0 & 31u) * 64u + (uint32_t)lane;  // slots 4t .. 4t+3 do not wrap
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) {
+                            float y[kWC], o[kWC];
+#pragma unroll
+                            for (int c = 0; c < kWC; ++c) y[c] = buf[lane][kWC * k + c];
+                            if (k == 0 && tx <= 1) {  // the line's inputs start at buffer column 2
+                                if (first) y[0] = y[1] = 0.0f;
+                            }
+                            w_run<kWC>(sC, cl, y, o);
+                            if (store) {
+                                buf_st(rs, csi + (2 * k) * 64, o[0]);
+                                buf_st(rs, csi + (2 * k + 1) * 64, o[8]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                wave_mem_sync();  // buf is rewritten by the next step
+            }
+            }
+            pass_d(3);  // sample columns 48..63 (slot 64 is the tail column's)
+        }
+    }
+}
+
 }  // namespace
 
 namespace hvd {
@@ -1130,13 +1537,29 @@ bool g_pdq_down512_strip64 = false;    // with split D: 64-column strips, 1 work
 bool g_pdq_down512_split_d = false;    // A/B switch: pass D as its own kernel (k_down512_d); same speed
 bool g_pdq_down512_systolic = false;  // A/B switch: k_down512s instead of k_down512
 bool g_pdq_fused_down512 = true;  // A/B switch (hvd_debug_set "pdq_fused_down512")
+int g_pdq_down512_wave = 1;       // k_down512w (one wave per frame): 0 never, 1 for batches >= 704 frames, 2 always
+int g_pdq_down512_wave_grid = 0;  // waves in flight; 0 = what is resident at once (rgb: 3 per SIMD, gray: 4)
 
 hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int w, int channels, float* d_ws,
                                  float* d_out64, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     if (h == kF && w == kF && g_pdq_fused_down512) {
         const unsigned grid = (unsigned)(n < 512 ? n : 512);  // 2 workgroups per CU fit by LDS (75.8 KB each)
-        if (g_pdq_down512_systolic) {
+        // one wave per frame (k_down512w) once there are enough frames to fill the chip with lone waves: a wave
+        // needs ~0.3 ms per frame whatever the load, a 512-lane workgroup ~0.2 ms, and the chip holds 3072 (rgb) /
+        // 4096 (gray) such waves but only 512 such workgroups; crossover measured at ~700 frames
+        // (profiles/r01_down512w_ablation.txt). pdq_down512_wave: 0 never, 1 by batch size (default), 2 always.
+        const bool use_wave = g_pdq_down512_wave == 2 || (g_pdq_down512_wave == 1 && n >= 704);
+        if (use_wave && !g_pdq_down512_systolic && !g_pdq_down512_split_d) {
+            // d_ws is sized for min(n, 1024) frames of the generic path (2.2 MB each) >= 19 KB per wave here
+            const int64_t resident = g_pdq_down512_wave_grid > 0 ? g_pdq_down512_wave_grid : 1024 * (channels == 3 ? 3 : 4);
+            const int64_t rounds = (n + resident - 1) / resident;  // equal shares: no half-empty last round
+            const unsigned gw = (unsigned)((n + rounds - 1) / rounds);
+            if (channels == 3)
+                hipLaunchKernelGGL(k_down512w<3>, dim3(gw), dim3(64), 0, s, d_frames, (long long)n, d_out64, d_ws);
+            else
+                hipLaunchKernelGGL(k_down512w<1>, dim3(gw), dim3(64), 0, s, d_frames, (long long)n, d_out64, d_ws);
+        } else if (g_pdq_down512_systolic) {
             const unsigned gs = (unsigned)(n < 256 ? n : 256);  // one workgroup per CU (LDS)
             if (channels == 3)
                 hipLaunchKernelGGL(k_down512s<3>, dim3(gs), dim3(kNW * 64), 0, s, d_frames, (long long)n, d_out64);

@@ -7,7 +7,7 @@ import hvd_amd
 from hvd_amd import _lib as L, synth
 lib = L.init(0)
 L.check(lib.hvd_debug_set(b"pdq_down512_systolic", int(sys.argv[1]) if len(sys.argv) > 1 else 0))
-n = 2048
+n = 6144
 base = synth.frames_rgb(16, seed=6)
 fr = np.concatenate([base] * (n // 16))
 sb = C.c_size_t(0); L.check(lib.hvd_pdq_scratch_bytes(n, 512, 512, 3, C.byref(sb)))

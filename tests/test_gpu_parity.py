@@ -530,25 +530,60 @@ def test_k2_full_size_10m_sharded_8_ways(gpu, hvd):
 
 
 def test_k1_down512_all_forms_agree(gpu, hvd, oracle):
-    """512x512 front-end: generic 4-launch path, fused strip kernel (default), split-D form,
-    64-column strips and the systolic kernel are interchangeable bit for bit (rgb24 and gray)."""
+    """512x512 front-end: generic 4-launch path, workgroup-per-frame strip kernel, split-D form, 64-column
+    strips, the systolic kernel and the wave-per-frame kernel (forced on: by default it only takes batches of
+    >= 704 frames) are interchangeable bit for bit (rgb24 and gray)."""
     lib = gpu.load()
     rgb = hvd.synth.frames_rgb(5, seed=91)
     gray = hvd.synth.frames_gray(5, seed=92, h=512, w=512)
     want_rgb = oracle.hash_frames(rgb, num_threads=8)
     want_gray = oracle.hash_frames(gray, num_threads=8)
-    keys = (b"pdq_fused_down512", b"pdq_down512_systolic", b"pdq_down512_split_d", b"pdq_down512_strip64")
+    keys = (b"pdq_fused_down512", b"pdq_down512_systolic", b"pdq_down512_split_d", b"pdq_down512_strip64",
+            b"pdq_down512_wave")
     try:
-        for cfg in ((0, 0, 0, 0), (1, 0, 0, 0), (1, 1, 0, 0), (1, 0, 1, 0), (1, 0, 1, 1)):
+        for cfg in ((0, 0, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 0, 0, 0), (1, 0, 1, 0, 0), (1, 0, 1, 1, 0), (1, 0, 0, 0, 2)):
             for k_, v_ in zip(keys, cfg):
                 gpu.check(lib.hvd_debug_set(k_, v_))
             for fr, (ho, qo) in ((rgb, want_rgb), (gray, want_gray)):
                 h, q = hvd.vpdq.hash_frames(fr)
                 assert np.array_equal(h, ho) and np.array_equal(q, qo), (cfg, fr.shape)
     finally:
-        for k_, v_ in zip(keys, (1, 0, 0, 0)):
+        for k_, v_ in zip(keys, (1, 0, 0, 0, 1)):
             gpu.check(lib.hvd_debug_set(k_, v_))
 
+
+@pytest.mark.parametrize("n,grid", [(1, 0), (3, 2), (64, 0), (130, 48), (200, 64)])
+@pytest.mark.parametrize("channels", [3, 1])
+def test_k1_down512_wave_kernel_vs_oracle(gpu, hvd, oracle, n, grid, channels):
+    """k_down512w (one wave per frame, skewed half-wave pipeline): every frame of ragged batches, with fewer waves
+    than frames (grid-stride loop, cross-frame prefetch) and on a fresh scratch buffer each time."""
+    lib = gpu.load()
+    fr = (hvd.synth.frames_rgb(n, seed=300 + n) if channels == 3 else hvd.synth.frames_gray(n, seed=400 + n, h=512, w=512))
+    if n >= 64:  # hard content too: noise, saturated blocks, a constant frame
+        rng = np.random.default_rng(n)
+        fr[1] = rng.integers(0, 256, fr[1].shape, dtype=np.uint8)
+        fr[2] = (rng.integers(0, 2, fr[2].shape) * 255).astype(np.uint8)
+        fr[3] = 255
+        fr[4] = 0
+    ho, qo = oracle.hash_frames(fr, num_threads=16)
+    try:
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_wave", 2))
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_wave_grid", grid))
+        h, q = hvd.vpdq.hash_frames(fr)
+    finally:
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_wave", 1))
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_wave_grid", 0))
+    assert np.array_equal(q, qo), f"{int((q != qo).sum())} quality mismatches"
+    assert np.array_equal(h, ho), f"{int((h != ho).any(1).sum())} hash mismatches"
+
+
+def test_k1_down512_large_batch_takes_the_wave_kernel(gpu, hvd, oracle):
+    """Default dispatch at a batch size that selects k_down512w (>= 704 frames): 768 rgb24 frames = 604 MB."""
+    base = hvd.synth.frames_rgb(48, seed=77)
+    fr = np.concatenate([base] * 16)
+    ho, qo = oracle.hash_frames(base, num_threads=16)
+    h, q = hvd.vpdq.hash_frames(fr)
+    assert np.array_equal(h, np.concatenate([ho] * 16)) and np.array_equal(q, np.concatenate([qo] * 16))
 
 
 @pytest.mark.parametrize("seed", range(12))
