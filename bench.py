@@ -310,12 +310,13 @@ def main():
     cpu = None
     if world == 1:
         # the reference's real frame geometry: 512x512 packed RGB24 (vpdqpy/vpdqpy.py:90-95)
-        n_rgb = 1024
+        n_rgb = 6144  # two full rounds of the 3072 resident waves of k_down512w (4.8 GB of frames)
         rgb = synth.frames_rgb(16, seed=6)
-        rgb = np.concatenate([rgb] * (n_rgb // 16))
         sb = C.c_size_t(0)
         L.check(lib.hvd_pdq_scratch_bytes(n_rgb, 512, 512, 3, C.byref(sb)))
-        d_rf = L.DeviceBuffer.from_array(rgb)
+        d_rf = L.DeviceBuffer(n_rgb * 786432)
+        for rep in range(n_rgb // 16):  # the 16 distinct frames, replicated on the device
+            L.check(lib.hvd_memcpy_h2d(C.c_void_p(d_rf.ptr + rep * rgb.nbytes), rgb.ctypes.data, rgb.nbytes))
         d_rs = L.DeviceBuffer(sb.value)
         d_rh = L.DeviceBuffer(32 * n_rgb)
         d_rq = L.DeviceBuffer(4 * n_rgb)
@@ -330,11 +331,14 @@ def main():
         rgb_fps = n_rgb / (rgb_ms * 1e-3)
         frames_out["rgb24_512x512"] = {
             "workload": f"{n_rgb} pre-decoded synthetic 512x512 RGB24 frames (the reference's hash_frame input): luma + "
-                        "2x Jarosz + decimate (k_down512) + k_pdq_hash64",
+                        "2x Jarosz + decimate (k_down512w, one wave per frame) + k_pdq_hash64",
             "value": float(f"{rgb_fps:.4g}"), "unit": "frames/s", "ms": round(rgb_ms, 3),
             "roofline": {"bound": "hbm", "achieved": round(rgb_fps * 786468 / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(rgb_fps * 786468 / 1e9 / HBM_PEAK_GBS, 3), "traffic": None,
-                         "note": "algorithmic bytes = 786432 in + 36 out per frame; the frame is read from HBM once"}}
+                         "note": "algorithmic bytes = 786432 in + 36 out per frame; the frame is read from HBM once. Not "
+                                 "HBM-bound yet: the same access shape streams at 6.2 TB/s (profiles/r01_ubench_hbm_runs.txt); "
+                                 "the kernel's own floor with L2-resident input is 5.7e6 frames/s "
+                                 "(profiles/r01_down512w_ablation.txt)"}}
         if not args.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
 
@@ -361,11 +365,12 @@ def main():
             qg = d_q.to_array(np.int32, args.frames)
             assert np.array_equal(hg, ho) and np.array_equal(qg, qo), "GPU frame hashes differ from the oracle"
             t = time.perf_counter()
-            hro, qro = O.hash_frames(rgb[:256], num_threads=cores)
+            hro, qro = O.hash_frames(np.concatenate([rgb] * 16), num_threads=cores)  # 256 frames
             dtr = time.perf_counter() - t
             hr = d_rh.to_array(np.uint8, 32 * n_rgb).reshape(-1, 32)
             qr = d_rq.to_array(np.int32, n_rgb)
-            assert np.array_equal(hr[:256], hro) and np.array_equal(qr[:256], qro), "GPU rgb512 hashes differ from the oracle"
+            assert (np.array_equal(hr, np.tile(hro[:16], (n_rgb // 16, 1))) and
+                    np.array_equal(qr, np.tile(qro[:16], n_rgb // 16))), "GPU rgb512 hashes differ from the oracle"
             frames_out["rgb24_512x512"]["cpu_frames_per_s"] = float(f"{256 / dtr:.4g}")
             cpu = {"value": float(f"{cpu_cmp:.4g}"), "unit": "comparisons/s", "cores": cores, "kind": "port",
                    "sample": f"oracle (C, popcnt, pthreads) all-pairs over the first {ns} of the {n} hashes "
