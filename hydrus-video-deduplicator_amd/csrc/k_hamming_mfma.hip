@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
                                                           const int32_t* __restrict__ group_t, float scale2) {
     constexpr uint32_t WROWS = 32u * TILES, ROWS = 4u * WROWS;
     constexpr int NB = PREFILTER ? 2 : 4;
-    __shared__ uint4 lds[2][kSuper * 8];
+    __shared__ uint4 lds0[kSuper * 8], lds1[kSuper * 8];
 
     const uint32_t rb = blockIdx.x, cb = blockIdx.y;
     const uint32_t row0 = rb * ROWS;
@@ -205,19 +205,16 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     const uint32_t j0 = RECT ? col0 : max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
     const uint32_t nsp = (col1 - j0) / kSuper;  // col0, col1, j0 are multiples of kSuper
 
-    stage_super_panel(img + (size_t)j0 * 8u, &lds[0][0], wave, lane);
-    __syncthreads();
-
-    for (uint32_t sp = 0; sp < nsp; ++sp) {
-        const uint32_t buf = sp & 1u;
-        const uint32_t jsp = j0 + sp * kSuper;
-        // buf^1 was last read in iteration sp-1, which every wave left through the barrier below
-        if (sp + 1u < nsp) stage_super_panel(img + (size_t)(jsp + kSuper) * 8u, &lds[buf ^ 1u][0], wave, lane);
-
+    // The two LDS buffers are separate objects and the super-panel loop is unrolled by two, so that every
+    // ds_read names one array and every in-flight global->LDS load the other: with one two-dimensional array
+    // the compiler could not tell them apart and put s_waitcnt vmcnt(0) in front of every panel's LDS reads,
+    // i.e. it waited for the prefetch of the NEXT super-panel before computing on this one.
+    auto process = [&](const uint4* __restrict__ panel, const uint32_t jsp) {
+        // (reading the next panel's B fragments one panel early was measured twice: +27 VGPRs and 3-6 % slower)
 #pragma unroll 1
         for (uint32_t p = 0; p < kSuper / 32; ++p) {
             const uint32_t cl = 32u * p + li;  // candidate index inside the super-panel
-            const uint4* base = &lds[buf][cl * 8u];
+            const uint4* base = &panel[cl * 8u];
             const uint32_t sw = (cl >> 1) & 7u;  // jsp is a multiple of 128: same swizzle as the global index
             v4i b[4];
 #pragma unroll
@@ -238,8 +235,21 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
                 panel_slow_path<TILES>(imgq, base, sw, wrow0, jsp + cl, n, h, li, group, thr_full, out, cap, count,
                                        RECT, nq, group_t, 1.0f / scale2);
         }
+    };
 
-        __syncthreads();  // (hipcc drains the in-flight global->LDS loads with vmcnt(0) first)
+    stage_super_panel(img + (size_t)j0 * 8u, lds0, wave, lane);
+    __syncthreads();
+
+    for (uint32_t sp = 0; sp < nsp; sp += 2) {
+        const uint32_t jsp = j0 + sp * kSuper;
+        // lds1 was last read in iteration sp-1, which every wave left through a barrier
+        if (sp + 1u < nsp) stage_super_panel(img + (size_t)(jsp + kSuper) * 8u, lds1, wave, lane);
+        process(lds0, jsp);
+        __syncthreads();  // (drains the in-flight global->LDS loads with vmcnt(0) first)
+        if (sp + 1u >= nsp) break;
+        if (sp + 2u < nsp) stage_super_panel(img + (size_t)(jsp + 2u * kSuper) * 8u, lds0, wave, lane);
+        process(lds1, jsp + kSuper);
+        __syncthreads();
     }
 }
 
