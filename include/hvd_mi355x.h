@@ -147,7 +147,14 @@ int hvd_dev_sync(void);
 int hvd_set_pdq_dct_mode(int mode);
 int hvd_get_pdq_dct_mode(void);
 
-/* Developer switches for A/B measurements ("pdq_dct_from_lds": 0|1). Results never change. */
+/* Developer switches for A/B measurements; results never change, only which kernel form runs:
+ *   "pdq_dct_from_lds" 0|1, "pdq_luma_lut" 0|1|2           (64x64 hash kernel)
+ *   "pdq_fused_down512" 0|1                                (0: generic 4-launch down-sampler)
+ *   "pdq_down512_wave" 0|1|2                               (wave-per-frame kernel: never | batches >= 704 | always)
+ *   "pdq_down512_wave_grid" n                              (waves in flight; 0 = what is resident at once)
+ *   "pdq_down512_systolic", "pdq_down512_split_d", "pdq_down512_strip64" 0|1   (workgroup-kernel variants)
+ *   "fp4_code", "mfma_col_chunk_max"                       (FP4-MFMA Hamming kernel)
+ * Unknown keys and out-of-range values return HVD_ERR_ARG. */
 int hvd_debug_set(const char* key, int value);
 
 /* Bytes of device scratch hvd_dev_pdq_hash_frames needs for this geometry (0 for
