@@ -64,6 +64,9 @@ struct Ctx {
     void* m_f = nullptr;
     void* m_o = nullptr;
     size_t m_a_cap = 0, m_b_cap = 0, m_f_cap = 0;
+    // pinned, device-visible staging of the small-operand path of hvd_match_two: operands, then the two counters
+    uint8_t* m_pin = nullptr;
+    int32_t m_seq = 0;
     std::mutex m_mu;
 };
 Ctx g;
@@ -197,6 +200,7 @@ int hvd_shutdown(void) {
     (void)hipStreamDestroy(g.stream);
     for (void** p : {&g.m_a, &g.m_b, &g.m_f, &g.m_o})
         if (*p) (void)hipFree(*p);
+    if (g.m_pin) (void)hipHostFree(g.m_pin);
     g.~Ctx();
     new (&g) Ctx();
     return HVD_OK;
@@ -622,6 +626,36 @@ int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, in
     if (!a || !b) return fail(HVD_ERR_ARG, "NULL hash buffer");
     // The VP-tree issues one such call per visited node (db/vptree.py:737): no malloc/free per call.
     std::lock_guard<std::mutex> lk(g.m_mu);
+    const size_t small = hvd::match_two_small_limit();
+    if (40 * (size_t)(na + nb) <= small) {
+        // operands fit in LDS: the kernel reads them from pinned host memory and writes the counters there, then a
+        // sequence word the host polls (a stream synchronisation costs more than the whole kernel)
+        if (!g.m_pin) {
+            HIP_TRY(hipHostMalloc((void**)&g.m_pin, small + 64, hipHostMallocDefault));
+            memset(g.m_pin + small, 0, 64);
+        }
+        uint8_t* pb = g.m_pin + 32 * (size_t)na;
+        volatile int32_t* ph = reinterpret_cast<volatile int32_t*>(g.m_pin + small);
+        memcpy(g.m_pin, a, 32 * (size_t)na);
+        memcpy(pb, b, 32 * (size_t)nb);
+        const int32_t seq = ++g.m_seq == 0 ? ++g.m_seq : g.m_seq;
+        HIP_TRY(hvd::launch_match_two_small((const uint32_t*)g.m_pin, (uint32_t)na, (const uint32_t*)pb, (uint32_t)nb,
+                                            (uint32_t)max_dist, (int32_t*)(g.m_pin + small), seq, g.stream));
+        bool seen = false;
+        for (long spin = 0; spin < 4000000; ++spin) {  // ~ms; a failed launch never writes the word
+            if (__atomic_load_n(&ph[2], __ATOMIC_ACQUIRE) == seq) {
+                seen = true;
+                break;
+            }
+        }
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            if (__atomic_load_n(&ph[2], __ATOMIC_ACQUIRE) != seq) return fail(HVD_ERR_HIP, "match kernel did not complete");
+        }
+        *q_hits = ph[0];
+        *t_hits = ph[1];
+        return HVD_OK;
+    }
     if (int rc = grow(&g.m_a, &g.m_a_cap, 32 * (size_t)na)) return rc;
     if (int rc = grow(&g.m_b, &g.m_b_cap, 32 * (size_t)nb)) return rc;
     if (int rc = grow(&g.m_f, &g.m_f_cap, 4 * (size_t)nb)) return rc;

@@ -38,6 +38,9 @@ bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, u
 
 hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t max_dist,
                             uint32_t* d_tflags, int32_t* d_hits, hipStream_t s);
+uint32_t match_two_small_limit();
+hipError_t launch_match_two_small(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t max_dist,
+                                  int32_t* hits, int32_t seq, hipStream_t s);
 
 // PDQ frame hashing. d_dct: 16*64 floats (host-computed, uploaded once).
 // kind 0: gray u8 64x64 frames; kind 1: float 64x64 buffers (output of the

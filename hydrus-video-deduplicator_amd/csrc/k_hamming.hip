@@ -211,6 +211,59 @@ __global__ __launch_bounds__(256) void k_match_two(const uint32_t* __restrict__ 
     }
 }
 
+// The same call for operands that fit in LDS (32 (na + nb) <= kMatchSmallBytes), which is every realistic video
+// hash (1 frame per second of video): a and b are read ONCE, coalesced, straight from the caller-visible pinned host
+// buffer the operands were copied into (no H2D copy command), compared out of LDS, and the two counters are written
+// back to pinned host memory (no D2H copy command): the call costs one launch and one stream synchronisation.
+// Rows of a are padded to 9 words so that 64 lanes reading 64 different rows hit 64 different banks; b is read at a
+// wave-uniform address (LDS broadcast).
+constexpr uint32_t kMatchSmallBytes = 56 * 1024;
+__global__ __launch_bounds__(256) void k_match_two_small(const uint32_t* __restrict__ a, uint32_t na,
+                                                         const uint32_t* __restrict__ b, uint32_t nb, uint32_t max_dist,
+                                                         int32_t* __restrict__ out_hits, int32_t seq) {
+    extern __shared__ uint32_t sm[];
+    uint32_t* sa = sm;                    // [na][9]
+    uint32_t* sb = sa + (size_t)na * 9u;  // [nb][9]
+    uint32_t* qf = sb + (size_t)nb * 9u;  // [na] hit flags of the query frames
+    uint32_t* tf = qf + na;               // [nb] hit flags of the target frames
+    __shared__ uint32_t s_q, s_t;
+    if (threadIdx.x == 0) {
+        s_q = 0;
+        s_t = 0;
+    }
+    for (uint32_t k = threadIdx.x; k < na * 8u; k += blockDim.x) sa[(k >> 3) * 9u + (k & 7u)] = a[k];
+    for (uint32_t k = threadIdx.x; k < nb * 8u; k += blockDim.x) sb[(k >> 3) * 9u + (k & 7u)] = b[k];
+    for (uint32_t j = threadIdx.x; j < na + nb; j += blockDim.x) qf[j] = 0u;
+    __syncthreads();
+    // every (query frame, target frame) pair is one work item: all 256 lanes are busy for any na, nb
+    const uint32_t total = na * nb;
+    for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) {
+        const uint32_t i = p / nb, j = p - i * nb;
+        const uint32_t* q = sa + i * 9u;
+        const uint32_t* c = sb + j * 9u;
+        uint32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) d += __popc(q[w] ^ c[w]);
+        if (d <= max_dist) {
+            qf[i] = 1u;  // benign races: all writers store 1
+            tf[j] = 1u;
+        }
+    }
+    __syncthreads();
+    uint32_t my_q = 0, my_t = 0;
+    for (uint32_t i = threadIdx.x; i < na; i += blockDim.x) my_q += qf[i];
+    for (uint32_t j = threadIdx.x; j < nb; j += blockDim.x) my_t += tf[j];
+    if (my_q) atomicAdd(&s_q, my_q);
+    if (my_t) atomicAdd(&s_t, my_t);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out_hits[0] = (int32_t)s_q;
+        out_hits[1] = (int32_t)s_t;
+        __threadfence_system();
+        __hip_atomic_store(&out_hits[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this word
+    }
+}
+
 }  // namespace
 
 namespace hvd {
@@ -281,6 +334,16 @@ hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s) {
 hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t max_dist,
                             uint32_t* d_tflags, int32_t* d_hits, hipStream_t s) {
     hipLaunchKernelGGL(k_match_two, dim3(1), dim3(256), 0, s, d_a, na, d_b, nb, max_dist, d_tflags, d_hits);
+    return hipGetLastError();
+}
+
+uint32_t match_two_small_limit() { return kMatchSmallBytes; }
+
+// a, b, hits: device-visible addresses of pinned host memory; hits[2] receives `seq` once hits[0..1] are final
+hipError_t launch_match_two_small(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t max_dist,
+                                  int32_t* hits, int32_t seq, hipStream_t s) {
+    const size_t lds = sizeof(uint32_t) * 10u * ((size_t)na + (size_t)nb);
+    hipLaunchKernelGGL(k_match_two_small, dim3(1), dim3(256), lds, s, a, na, b, nb, max_dist, hits, seq);
     return hipGetLastError();
 }
 

@@ -351,6 +351,17 @@ def test_match_two_vs_oracle(gpu, hvd, oracle):
         assert hvd.vpdq.match_counts(ba, bb, 31) == oracle.match_two(ba, bb, 31)
 
 
+@pytest.mark.parametrize("na,nb", [(1, 1), (1, 300), (257, 3), (700, 733), (717, 717), (800, 800), (5, 3000)])
+def test_match_two_small_and_large_operand_paths(gpu, hvd, oracle, na, nb):
+    """hvd_match_two compares out of LDS, straight from pinned host memory, while 40 (na + nb) <= 56 KiB (1433 frames)
+    and through device buffers beyond; both must give the oracle's counters, at several tolerances."""
+    fr, _ = hvd.synth.hash_db(na + nb, seed=na * 7 + nb, plant_fraction=0.3)
+    a, b = fr[:na].tobytes(), fr[na:].tobytes()
+    for tol in (0, 31, 90):
+        assert hvd.vpdq.match_counts(a, b, tol) == oracle.match_two(a, b, tol), (na, nb, tol)
+    assert hvd.vpdq.match_counts(a, a, 0) == (na, na) or len(set(map(bytes, fr[:na]))) < na
+
+
 def test_match_hash_semantics(gpu, hvd):
     g = load_golden("video_match.npz")
     v = hvd.VpdqHash(g["frames"][:12].tobytes())
