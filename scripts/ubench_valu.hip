@@ -49,6 +49,8 @@ BODY(k_cmp, asm volatile("v_cmp_le_u32 vcc, %0, %1" : : "v"(v[c]), "v"(v[(c + 1)
     __global__ __launch_bounds__(256) void NAME(uint32_t* out, uint32_t seed) {         \
         typedef float f2 __attribute__((ext_vector_type(2)));                           \
         f2 v[CHAINS];                                                                   \
+        f2 sp; sp.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(seed | 0x3f800000u)); \
+        sp.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((seed << 3) | 0x3f800000u)); \
         _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) { v[c].x = threadIdx.x + c + seed; v[c].y = c; } \
         for (int it = 0; it < ITERS; ++it) {                                            \
             _Pragma("unroll") for (int u = 0; u < 4; ++u) {                             \
@@ -62,6 +64,9 @@ BODY(k_cmp, asm volatile("v_cmp_le_u32 vcc, %0, %1" : : "v"(v[c]), "v"(v[(c + 1)
 BODY2(k_pk_mul, asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v[c]) : "v"(v[(c + 1) % CHAINS])))
 BODY2(k_pk_add, asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v[c]) : "v"(v[(c + 1) % CHAINS])))
 BODY2(k_pk_fma, asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(v[c]) : "v"(v[(c + 1) % CHAINS])))
+// packed multiply with the other operand pair in SGPRs (what a DCT row held in scalar registers would use)
+BODY2(k_pk_mul_sv, asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(v[c]) : "s"(sp)))
+BODY2(k_pk_mul_sv_lo, asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel_hi:[0,1]" : "+v"(v[c]) : "s"(sp)))
 
 typedef void (*kern_t)(uint32_t*, uint32_t);
 
@@ -81,6 +86,7 @@ int main() {
         {"v_fma_f32", k_fmaf, 1}, {"v_mul_f32 s,v", k_mul_sv, 1}, {"v_sad_u8", k_sad, 1},
         {"v_dot4_i32_i8", k_dot4, 1}, {"v_dot8_i32_i4", k_dot8, 1}, {"v_cmp_le_u32", k_cmp, 1},
         {"v_pk_mul_f32", k_pk_mul, 1}, {"v_pk_add_f32", k_pk_add, 1}, {"v_pk_fma_f32", k_pk_fma, 1},
+        {"v_pk_mul_f32 s[2],v[2]", k_pk_mul_sv, 1}, {"v_pk_mul_f32 s[2],v[2] opsel", k_pk_mul_sv_lo, 1},
     };
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
