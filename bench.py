@@ -142,8 +142,14 @@ def main():
             hard_exit = th.is_alive()
 
     def barrier():
+        # the kernels run on the library's own HIP stream, which hvd_dev_sync() drains; torch's device-wide
+        # synchronize is added when torch is loaded anyway (N > 1) so that nothing of any stream is in flight
         L.check(lib.hvd_dev_sync())
         if dist is not None:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
             dist.barrier()
 
     variant = search.DEFAULT_VARIANT if args.variant < 0 else args.variant
