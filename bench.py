@@ -149,7 +149,7 @@ def main():
             import torch
 
             if torch.cuda.is_available():
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(dev)  # this rank's GPU only
             dist.barrier()
 
     variant = search.DEFAULT_VARIANT if args.variant < 0 else args.variant
