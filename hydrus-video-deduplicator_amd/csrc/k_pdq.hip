@@ -1105,9 +1105,10 @@ __global__ __launch_bounds__(kNW * 64) void k_down512s(const uint8_t* __restrict
 //                     lower half walked one step earlier (state handed over by a 32-lane shuffle);
 //                     across tile rows the state goes through a small per-wave global scratch.
 //   C  lane = row     rep-2 filter along the row; only the 4 decimation samples per row and step are
-//                     kept, in the per-wave sample ring cs[slot & 31][row] (global, coalesced, L2-resident)
-//   D  lane = sample column j, 16 columns every fourth step: the samples come back through the idle
-//                     buffer, rep-2 filter down the 64 rows, emits out64[i][j] at the 8 sampled rows
+//                     kept (1 KB of LDS)
+//   D  lane j = sample column j: rep-2 filter down the rows of its column, 32 rows in the step that
+//                     produced them (lower half) and 32 in the next (upper half); the running sum lives in
+//                     the lane's registers for the whole frame; emits out64[i][j] at the 8 sampled rows
 // Column tile 16 and tile row 8 are the tails of box1DFloat's phase 4 (one column / one row of each is
 // needed by the decimation). Starting a line is the steady step on an all-zero state (0 + x and
 // x - 0 are exact), so only the two /3 outputs per line are special.
@@ -1122,7 +1123,7 @@ constexpr int kWNX = kF / kWT;                          // full column tiles (16
 constexpr int kWNY = kF / kWR;                          // full tile rows (8); index 8 = tail
 constexpr int kWC = 16;                                 // elements per register chunk of a pass
 constexpr int kWStateFloats = (kWNX + 1) * 5 * 32;      // pass-B state: [column tile][5][column]
-constexpr int kWScratchFloats = kWStateFloats + 32 * 64;  // + the ring of C samples: [slot & 31][row]
+constexpr int kWScratchFloats = kWStateFloats;
 
 __device__ __forceinline__ void wave_mem_sync() {  // stores of this wave become visible to its other lanes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1228,15 +1229,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
     __shared__ __attribute__((aligned(16))) float buf[kWR][LD];
     static_assert(sizeof(buf) >= 32 * TileLoad<CH>::RS, "the byte staging aliases the transposition buffer");
     __shared__ __attribute__((aligned(16))) uint8_t park[32 * TileLoad<CH>::RS];
+    // this step's C samples [slot % 4][row] alias the transposition buffer: C writes them after its last read of buf
+    float (*smp)[kWR] = reinterpret_cast<float (*)[kWR]>(&buf[0][0]);
+    static_assert(sizeof(buf) >= 4 * kWR * sizeof(float), "smp aliases buf");
     constexpr int SQ = TileLoad<CH>::SQ;
     static_assert(SQ == NCH * QPC, "a step is NCH chunks of QPC pieces");
     uint8_t* stage = reinterpret_cast<uint8_t*>(&buf[0][0]);
     const int lane = threadIdx.x;
     const int half = lane >> 5, cl5 = lane & 31;
-    // per-wave scratch: pass-B state [17][5][32], then the ring of C samples [32 slots][64 rows]
+    // per-wave scratch: pass-B state [17][5][32]
     const __amdgpu_buffer_rsrc_t rs =
         make_rsrc(wscratch + (size_t)blockIdx.x * kWScratchFloats, kWScratchFloats * sizeof(float));
-    constexpr uint32_t kCs = kWStateFloats;
     constexpr uint32_t row_bytes = kF * CH, frame_bytes = kF * kF * CH;
 
     // two prefetch buffers: pre[0] always holds the lower half's next unit, pre[1] the upper half's; each is
@@ -1274,52 +1277,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
             }
             const uint32_t rbase = (uint32_t)(kWR * ty) * row_bytes;  // byte offset of the tile row in the frame
 
-            // ---------------- D: rep-2 down 16 sample columns at a time (lane = j) ----------------------------
-            // After step 4c+5 both halves are through slots <= 16c+19, so slots 16c+1 .. 16c+16 <-> sample columns
-            // j = 16c .. 16c+15 <-> lanes 16c .. 16c+15 can run (each lane owns one column for the whole frame: its
-            // running sum lives in the same registers from tile row to tile row). It runs at the TOP of step 4c+6,
-            // before that step's frame fetch is issued: vmcnt retires in order, so waiting for these loads any later
-            // would also wait for a fetch that has only just left. Consuming the samples this soon keeps the ring small
-            // (8 KB per wave, L2-resident). The samples come back row-per-lane (coalesced) and turn through the idle
-            // buffer: buf[row][slot]. Row r <-> input row Y = 64ty-2+r; output Y-2 is decimation row i = 8ty-1+r/8
-            // iff r % 8 == 0.
-            auto pass_d = [&](const int c16) {
-                    float t[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    t[e] = buf_ld(rs, kCs + (uint32_t)(((16 * c16 + 1 + e) & 31) * 64 + lane));
-#pragma unroll
-                for (int e = 0; e < 16; ++e) buf[lane][e] = t[e];
-                wave_mem_sync();
-                const int jl = lane - 16 * c16;
-                if (jl >= 0 && jl < 16) {
-                    if (ty < kWNY) {
-#pragma unroll
-                        for (int k = 0; k < kWR / kWC; ++k) {
-                            float zz[kWC], o[kWC];
-#pragma unroll
-                            for (int r = 0; r < kWC; ++r) zz[r] = buf[kWC * k + r][jl];
-                            if (k == 0 && ty == 0) zz[0] = zz[1] = 0.0f;  // the line's inputs start at row 2
-                            w_run<kWC>(sD, dl, zz, o);
-                            if (k > 0 || ty > 0) buf_st(rd, (uint32_t)((8 * ty - 1 + 2 * k) * 64 + lane), __fmul_rn(o[0], 0x1p-8f));
-                            buf_st(rd, (uint32_t)((8 * ty + 2 * k) * 64 + lane), __fmul_rn(o[8], 0x1p-8f));
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    } else {  // Y = 510 (row 0 of the tail tile row): output 508 = decimation row 63
-                        sD = __fsub_rn(__fadd_rn(sD, buf[0][jl]), dl[0]);
-                        buf_st(rd, (uint32_t)(63 * 64 + lane), __fmul_rn(sD, 0x1p-8f));
-                    }
-                }
-                wave_mem_sync();  // buf is rewritten by the next step
-            };
-
 #pragma unroll 1
             for (int tp = 0; tp <= kWNX + 1; tp += 2) {
 #pragma unroll
             for (int par = 0; par < 2; ++par) {  // even / odd step: static after unrolling (prefetch buffer, refilling half)
                 const int tx = tp + par;
                 const int txl = tx - half;  // the column tile this lane works on in this step
-                if (par == 0 && (tx & 3) == 2 && tx >= 6) pass_d((tx - 6) >> 2);
                 // pass-B state of the lower half for this step: left by the upper half one tile row up; the
                 // load is issued here so that its latency hides behind pass A
                 // (vmcnt retires in order: a wait for these small loads also waits for every load issued before
@@ -1451,22 +1414,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
 
                 // ---------------- C: rep-2 along the row over the buffer columns (lane = buffer row) -------
                 // buffer column c <-> input index X = 32t-2+c; output X-2 is decimation sample j = 4t-1+c/8 iff c
-                // is a multiple of 8 -> sample slot 4t + c/8 (slot 0 = j -1 does not exist). The samples go to
-                // the per-wave ring cs[slot & 31][row] in global memory (one 256-byte row per slot: coalesced).
-                // Lanes whose row does not exist (ty = 0: r < 2; ty = 8: r > 0) compute on leftovers; D ignores them.
+                // is a multiple of 8 -> sample slot 4t + c/8 (slot 0 = j -1 does not exist). The step's 4 samples
+                // of every row go to smp[slot % 4][row] in LDS for pass D below. Lanes whose row does not exist
+                // (ty = 0: r < 2; ty = 8: r > 0) compute on leftovers; D ignores them.
                 {
-                    const uint32_t slot0 = (uint32_t)(txl < 0 ? 0 : txl) * 4u;
-                    if (tx >= kWNX && txl == kWNX) {  // X = 510: output 508 = sample column 63 (slot 64)
-                        buf_st(rs, kCs + (slot0 & 31u) * 64u + (uint32_t)lane, __fsub_rn(__fadd_rn(sC, buf[lane][0]), cl[0]));
-                    }
+                    float sv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    const bool tail = (tx >= kWNX) && (txl == kWNX);
+                    if (tail) sv[0] = __fsub_rn(__fadd_rn(sC, buf[lane][0]), cl[0]);  // X = 510: output 508 = sample column 63 (slot 64)
+                    const bool store = (txl >= 0) && (txl < kWNX);
                     if (tx <= kWNX) {
                         const bool first = (tx <= 1) && (txl == 0);
                         if (first) {
                             sC = 0.0f;
                             cl[0] = cl[1] = cl[2] = cl[3] = 0.0f;
                         }
-                        const bool store = (txl >= 0) && (txl < kWNX);
-                        const uint32_t csi = kCs + (slot0 & 31u) * 64u + (uint32_t)lane;  // slots 4t .. 4t+3 do not wrap
 #pragma unroll
                         for (int k = 0; k < NCH; ++k) {
                             float y[kWC], o[kWC];
@@ -1477,17 +1438,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                             }
                             w_run<kWC>(sC, cl, y, o);
                             if (store) {
-                                buf_st(rs, csi + (2 * k) * 64, o[0]);
-                                buf_st(rs, csi + (2 * k + 1) * 64, o[8]);
+                                sv[2 * k] = o[0];
+                                sv[2 * k + 1] = o[8];
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    wave_mem_sync();  // every lane has read its buffer row; the samples may now overwrite it
+                    if (store) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) smp[k][lane] = sv[k];
+                    } else if (tail) {
+                        smp[0][lane] = sv[0];
+                    }
                 }
-                wave_mem_sync();  // buf is rewritten by the next step
+                wave_mem_sync();  // buf is rewritten by the next step; smp is read below
+
+                // ---------------- D: rep-2 down the sample columns (lane j owns sample column j = slot j+1) ----
+                // Slot group g = slot/4 is produced by the lower half (rows 0..31) in step g and by the upper half
+                // (rows 32..63) in step g+1; its four owner lanes run their 32 rows right away, in both steps. The
+                // running sum of a column therefore never leaves its lane's registers, within the tile row and from
+                // tile row to tile row, and the samples never leave LDS (a global sample ring cost 0.3 MB of
+                // memory-side traffic per frame). Only 8 of 64 lanes work here: ~13 % more instructions, the price
+                // of not transposing through memory. Row r <-> input row Y = 64ty-2+r; output Y-2 is decimation row
+                // i = 8ty-1+r/8 iff r % 8 == 0.
+                {
+                    const int js = lane + 1, gs = js >> 2;
+                    const bool lo_pass = (gs == tx) && (tx <= kWNX), hi_pass = (gs == tx - 1);
+                    if (lo_pass || hi_pass) {
+                        const int r0 = hi_pass ? 32 : 0;
+                        const float* zp = &smp[js & 3][r0];
+                        if (ty < kWNY) {
+#pragma unroll
+                            for (int k = 0; k < 32 / kWC; ++k) {
+                                float z[kWC], o[kWC];
+#pragma unroll
+                                for (int r = 0; r < kWC; ++r) z[r] = zp[kWC * k + r];
+                                if (k == 0 && ty == 0) {  // the line's inputs start at row 2 of the first tile row
+                                    if (lo_pass) z[0] = z[1] = 0.0f;
+                                }
+                                w_run<kWC>(sD, dl, z, o);
+                                const int ib = 8 * ty - 1 + ((r0 + kWC * k) >> 3);
+                                if (ib >= 0) buf_st(rd, (uint32_t)(ib * 64 + lane), __fmul_rn(o[0], 0x1p-8f));
+                                buf_st(rd, (uint32_t)((ib + 1) * 64 + lane), __fmul_rn(o[8], 0x1p-8f));
+                            }
+                        } else if (lo_pass) {  // Y = 510 (row 0 of the tail tile row): output 508 = decimation row 63
+                            sD = __fsub_rn(__fadd_rn(sD, zp[0]), dl[0]);
+                            buf_st(rd, (uint32_t)(63 * 64 + lane), __fmul_rn(sD, 0x1p-8f));
+                        }
+                    }
+                }
+                wave_mem_sync();  // smp is rewritten by the next step
             }
             }
-            pass_d(3);  // sample columns 48..63 (slot 64 is the tail column's)
         }
     }
 }
@@ -1551,8 +1554,9 @@ hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int 
         // (profiles/r01_down512w_ablation.txt). pdq_down512_wave: 0 never, 1 by batch size (default), 2 always.
         const bool use_wave = g_pdq_down512_wave == 2 || (g_pdq_down512_wave == 1 && n >= 704);
         if (use_wave && !g_pdq_down512_systolic && !g_pdq_down512_split_d) {
-            // d_ws is sized for min(n, 1024) frames of the generic path (2.2 MB each) >= 19 KB per wave here
-            const int64_t resident = g_pdq_down512_wave_grid > 0 ? g_pdq_down512_wave_grid : 1024 * (channels == 3 ? 3 : 4);
+            // d_ws is sized for min(n, 1024) frames of the generic path (2.2 MB each) >= 10.9 KB per wave here.
+            // resident waves: rgb 12 per CU (168 VGPRs, 13 KB of LDS), gray 16 per CU (10 KB of LDS)
+            const int64_t resident = g_pdq_down512_wave_grid > 0 ? g_pdq_down512_wave_grid : 256 * (channels == 3 ? 12 : 16);
             const int64_t rounds = (n + resident - 1) / resident;  // equal shares: no half-empty last round
             const unsigned gw = (unsigned)((n + rounds - 1) / rounds);
             if (channels == 3)
