@@ -300,18 +300,6 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_pdq_down512_wave_grid = value;
         return HVD_OK;
     }
-    if (strcmp(key, "pdq_down512_strip64") == 0) {
-        hvd::g_pdq_down512_strip64 = value != 0;
-        return HVD_OK;
-    }
-    if (strcmp(key, "pdq_down512_split_d") == 0) {
-        hvd::g_pdq_down512_split_d = value != 0;
-        return HVD_OK;
-    }
-    if (strcmp(key, "pdq_down512_systolic") == 0) {
-        hvd::g_pdq_down512_systolic = value != 0;
-        return HVD_OK;
-    }
     if (strcmp(key, "pdq_fused_down512") == 0) {
         hvd::g_pdq_fused_down512 = value != 0;
         return HVD_OK;

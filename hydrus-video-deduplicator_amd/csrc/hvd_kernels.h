@@ -49,9 +49,6 @@ extern bool g_pdq_dct_from_lds;
 extern int g_pdq_luma_lut;
 extern int g_pdq_dct_mode;
 extern bool g_pdq_fused_down512;
-extern bool g_pdq_down512_systolic;
-extern bool g_pdq_down512_split_d;
-extern bool g_pdq_down512_strip64;
 extern int g_pdq_down512_wave;
 extern int g_pdq_down512_wave_grid;
 hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,

@@ -645,18 +645,17 @@ __device__ __forceinline__ void column_pass512(float* col, const int stride, flo
 }
 #undef HVD_COL_STEP
 
-// SPLITD: pass D (64 sample columns per frame, but a whole wave's instruction stream per strip when
-// run 4 lanes wide next to B) is left to k_down512_d; C then writes its samples to csamp[frame][j][row].
-// S: strip width (32: 2 workgroups/CU, B on half a wave; 64 (SPLITD only): 1 workgroup/CU, B on a full
-// wave and half as many B phases).
-template <int CH, bool SPLITD, int S>
-__global__ __launch_bounds__(512, (S == 32 ? 4 : 2)) void k_down512(  // S=32: 2 workgroups/CU => <= 128 VGPRs
-    const uint8_t* __restrict__ frames, long long n, float* __restrict__ out64, float* __restrict__ csamp) {
-    static_assert(S == 32 || (S == 64 && SPLITD), "64-column strips need the split D pass (no room for cs)");
+// (Measured and dropped, profiles/r01_pmc_down512.txt: pass D as its own kernel -- same speed; 64-column strips with
+// one workgroup per CU -- 15 % slower; a 9-wave systolic form with LDS mailboxes -- same speed. The lever turned out
+// to be a different decomposition altogether: k_down512w below.)
+template <int CH>
+__global__ __launch_bounds__(512, 4) void k_down512(  // 2 workgroups/CU => <= 128 VGPRs
+    const uint8_t* __restrict__ frames, long long n, float* __restrict__ out64) {
+    constexpr int S = kS;
     constexpr int NST = kF / S;       // full strips; strip NST holds the two tail columns
     constexpr int SPS = S / 8;        // decimation samples per strip
     __shared__ float buf[kF][S + 1];
-    __shared__ float cs[SPLITD ? 1 : 4][SPLITD ? 1 : kCsLd];
+    __shared__ float cs[4][kCsLd];
     const int y = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -664,7 +663,6 @@ __global__ __launch_bounds__(512, (S == 32 ? 4 : 2)) void k_down512(  // S=32: 2
     for (long long f = blockIdx.x; f < n; f += gridDim.x) {
         const uint8_t* row_ptr = frames + (size_t)f * kF * kF * CH + (size_t)y * kF * CH;
         float* dst = out64 + (size_t)f * 4096;
-        float* cg = csamp + (size_t)f * 64 * kF;  // SPLITD: C samples [sample column j][row]
         float sA = 0.0f, lagA[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float sC = 0.0f, lagC[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         StripRaw<CH, S> raw;
@@ -720,7 +718,7 @@ __global__ __launch_bounds__(512, (S == 32 ? 4 : 2)) void k_down512(  // S=32: 2
             } else if (wave == 1 && k > 0) {
                 // D: samples written by C of strip k-1: slot jj <-> sample column j = 4(k-1) - 1 + jj
                 const int jj = lane, j = SPS * (k - 1) - 1 + jj;
-                if (!SPLITD && jj < 4 && j >= 0 && j < 64) column_pass512<false>(cs[jj], 1, dst, j);
+                if (jj < 4 && j >= 0 && j < 64) column_pass512<false>(cs[jj], 1, dst, j);
             }
             __syncthreads();
 
@@ -737,13 +735,7 @@ __global__ __launch_bounds__(512, (S == 32 ? 4 : 2)) void k_down512(  // S=32: 2
                     const float x = buf[y][c];
                     sC = __fsub_rn(__fadd_rn(sC, x), lagC[(c + 2) & 3]);
                     lagC[(c + 2) & 3] = x;
-                    if ((c & 7) == 0) {
-                        if (SPLITD) {
-                            if (SPS * k - 1 + (c >> 3) >= 0) cg[(size_t)(SPS * k - 1 + (c >> 3)) * kF + y] = __fmul_rn(sC, 0.25f);
-                        } else {
-                            cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
-                        }
-                    }
+                    if ((c & 7) == 0) cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
                 }
             } else if (k < NST) {
 #pragma unroll
@@ -751,339 +743,24 @@ __global__ __launch_bounds__(512, (S == 32 ? 4 : 2)) void k_down512(  // S=32: 2
                     const float x = buf[y][c];
                     sC = __fsub_rn(__fadd_rn(sC, x), lagC[(c + 2) & 3]);
                     lagC[(c + 2) & 3] = x;
-                    if ((c & 7) == 0) {
-                        if (SPLITD) {
-                            if (SPS * k - 1 + (c >> 3) >= 0) cg[(size_t)(SPS * k - 1 + (c >> 3)) * kF + y] = __fmul_rn(sC, 0.25f);
-                        } else {
-                            cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
-                        }
-                    }
+                    if ((c & 7) == 0) cs[c >> 3][y] = __fmul_rn(sC, 0.25f);
                 }
             } else {
                 // t = 510: output 508 = sample column 63 (slot 0); t = 511 feeds nothing that is sampled
                 const float x = buf[y][0];
                 sC = __fsub_rn(__fadd_rn(sC, x), lagC[2]);
-                if (SPLITD)
-                    cg[(size_t)63 * kF + y] = __fmul_rn(sC, 0.25f);
-                else
-                    cs[0][y] = __fmul_rn(sC, 0.25f);
+                cs[0][y] = __fmul_rn(sC, 0.25f);
             }
             __syncthreads();
         }
 
         // D for the last strip's single sample column (j = 63)
-        if (!SPLITD && wave == 1 && lane == 0) column_pass512<false>(cs[0], 1, dst, 63);
+        if (wave == 1 && lane == 0) column_pass512<false>(cs[0], 1, dst, 63);
         __syncthreads();  // cs / buf are reused by the next frame
     }
 }
 
 
-
-// Pass D for SPLITD: one wave per frame, lane = sample column j (64 of them), the 512 rows of
-// csamp[frame][j][.] streamed through LDS in tiles of 64 rows (coalesced loads, conflict-free
-// transposed reads). Only the outputs oy = 8i+4 (step s = 8i+6) are emitted.
-__global__ __launch_bounds__(64) void k_down512_d(const float* __restrict__ csamp, long long n,
-                                                  float* __restrict__ out64) {
-    __shared__ float tile[64][65];
-    const int j = threadIdx.x;
-    for (long long f = blockIdx.x; f < n; f += gridDim.x) {
-        const float* src = csamp + (size_t)f * 64 * kF;
-        float* dst = out64 + (size_t)f * 4096;
-        float sum = 0.0f, l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, l3 = 0.0f;
-#pragma unroll 1
-        for (int y0 = 0; y0 < kF; y0 += 64) {
-            __syncthreads();
-#pragma unroll 8
-            for (int c = 0; c < 64; ++c) tile[c][j] = src[(size_t)c * kF + y0 + j];  // row c of the tile = column c
-            __syncthreads();
-            const float* col = &tile[j][0];
-            if (y0 == 0) {
-                const float x0 = col[0], x1 = col[1], x2 = col[2], x3 = col[3];
-                sum = __fadd_rn(__fadd_rn(__fadd_rn(x0, x1), x2), x3);
-                l0 = x0; l1 = x1; l2 = x2; l3 = x3;
-#pragma unroll
-                for (int q = 4; q < 64; q += 4) {
-                    const float a0 = col[q], a1 = col[q + 1], a2 = col[q + 2], a3 = col[q + 3];
-                    sum = __fsub_rn(__fadd_rn(sum, a0), l0); l0 = a0;
-                    sum = __fsub_rn(__fadd_rn(sum, a1), l1); l1 = a1;
-                    sum = __fsub_rn(__fadd_rn(sum, a2), l2); l2 = a2;
-                    if ((q & 7) == 4) dst[((q - 4) >> 3) * 64 + j] = __fmul_rn(sum, 0.25f);  // step q+2 = 8i+6
-                    sum = __fsub_rn(__fadd_rn(sum, a3), l3); l3 = a3;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 64; q += 4) {
-                    const float a0 = col[q], a1 = col[q + 1], a2 = col[q + 2], a3 = col[q + 3];
-                    sum = __fsub_rn(__fadd_rn(sum, a0), l0); l0 = a0;
-                    sum = __fsub_rn(__fadd_rn(sum, a1), l1); l1 = a1;
-                    sum = __fsub_rn(__fadd_rn(sum, a2), l2); l2 = a2;
-                    if ((q & 7) == 4) dst[((y0 + q - 4) >> 3) * 64 + j] = __fmul_rn(sum, 0.25f);
-                    sum = __fsub_rn(__fadd_rn(sum, a3), l3); l3 = a3;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// k_down512s: systolic form of the fused 512x512 down-sampler.
-//
-// k_down512 serialises the column recurrence of each strip on one wave. Here every filter
-// output is stored at the index of the STEP that produced it ("label" = true index + 2: the
-// running-sum filter's output lags its input by 2), which makes all four passes tile-aligned:
-// tile (r, c) = label rows [64r, 64r+64) x label columns [32c, 32c+32), r = 0..8, c = 0..16
-// (row band 8 / column 16 hold only the two tail labels 512, 513). For a tile:
-//   A  lane = input row,    32 steps along the row   -> X[row][col]   (state: registers, per band)
-//   B  lane = label column, 64 steps down the rows   -> X in place    (state: from the band above)
-//   C  lane = label row,    32 steps along the row   -> Z[sample][row] (state: registers, per band)
-//   D  lane = sample column, 64 steps down the rows  -> out64          (state: from the band above)
-// Wave r owns row band r for the whole frame and walks c = 0..16; B/D state moves from wave
-// r-1 to wave r through an LDS mailbox, so wave r runs one tile column behind wave r-1
-// (global step t: wave r works on c = t - r). B (lanes 0..31) and D of the previous tile column
-// (lanes 32..35) share one instruction stream. One workgroup barrier per step (26 per frame);
-// X and Z are wave-private. Operation order per filter is upstream's box1DFloat, so the result
-// is bit-identical to k_down512, the generic path and the oracle.
-constexpr int kTR = 64, kTC = 32, kNW = 9;
-
-struct Run5 {
-    float sum, l0, l1, l2, l3;
-};
-
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-#define HVD_RUN_STEP(X_, L_)                 \
-    st.sum = __fadd_rn(st.sum, (X_));        \
-    st.sum = __fsub_rn(st.sum, (L_));        \
-    (L_) = (X_);
-
-// 64 steady-state steps down a column (every step adds the new value and drops the one four
-// steps back). Every lane stores its output in place; lanes with emit = true also write the
-// decimation samples (label row a multiple of 8) to dst[(i0 + q/8) * 64 + j].
-__device__ __forceinline__ void colpass64_steady(float* p, const int stride, Run5& st, const bool emit,
-                                                 float* __restrict__ dst, const int i0, const int j) {
-    float a[8], b[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = p[e * stride];
-#define HVD_RUN_CHUNK(V, Q0)                                                                       \
-    {                                                                                              \
-        float o[8];                                                                                \
-        HVD_RUN_STEP(V[0], st.l0) o[0] = st.sum; HVD_RUN_STEP(V[1], st.l1) o[1] = st.sum;          \
-        HVD_RUN_STEP(V[2], st.l2) o[2] = st.sum; HVD_RUN_STEP(V[3], st.l3) o[3] = st.sum;          \
-        HVD_RUN_STEP(V[4], st.l0) o[4] = st.sum; HVD_RUN_STEP(V[5], st.l1) o[5] = st.sum;          \
-        HVD_RUN_STEP(V[6], st.l2) o[6] = st.sum; HVD_RUN_STEP(V[7], st.l3) o[7] = st.sum;          \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) p[((Q0) + e) * stride] = __fmul_rn(o[e], 0.25f); \
-        if (emit) dst[(i0 + ((Q0) >> 3)) * 64 + j] = __fmul_rn(o[0], 0.25f);                       \
-    }
-#pragma unroll 1
-    for (int q0 = 0; q0 < 64; q0 += 16) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b[e] = p[(q0 + 8 + e) * stride];
-        HVD_RUN_CHUNK(a, q0)
-        if (q0 + 16 < 64) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = p[(q0 + 16 + e) * stride];
-        }
-        HVD_RUN_CHUNK(b, q0 + 8)
-    }
-}
-
-template <int CH>
-__global__ __launch_bounds__(kNW * 64) void k_down512s(const uint8_t* __restrict__ frames, long long n,
-                                                       float* __restrict__ out64) {
-    __shared__ float X[kNW][kTR][kTC + 1];       // wave-private tile: A output, then B output in place
-    __shared__ float Z[kNW][2][4][kTR + 1];      // wave-private decimation-column samples of C, double buffered
-    __shared__ float mbB[kNW][2][5][kTC];        // column-pass state leaving wave r (slot = step parity)
-    __shared__ float mbD[kNW][2][5][4];
-    __shared__ float dummy[64 * 9];              // scratch column for lanes without column work
-
-    const int lane = threadIdx.x & 63;
-    const int r = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row band of this wave
-    const bool isB = lane < kTC;
-    const bool isD = lane >= kTC && lane < kTC + 4;
-    const int jj = lane - kTC;
-
-    for (long long f = blockIdx.x; f < n; f += gridDim.x) {
-        const uint8_t* row_ptr = frames + (size_t)f * kF * kF * CH + (size_t)(r < 8 ? 64 * r + lane : 0) * kF * CH;
-        float* dst = out64 + (size_t)f * 4096;
-        float sA = 0.0f, lagA[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        float sC = 0.0f, lagC[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        StripRaw<CH> raw;
-        if (r < 8) load_strip_raw<CH>(row_ptr, 0, raw);
-
-#pragma unroll 1
-        for (int t = 0; t <= 8 + 17; ++t) {
-            const int c = t - r;  // tile column of this wave in this step (wave-uniform)
-
-            // ---------------- A: rep-1 along the input row ------------------------------------
-            if (r < 8 && c >= 0 && c <= 16) {
-                float* xrow = &X[r][lane][0];
-                if (c < 16) {
-                    float v[kS];
-                    strip_luma<CH>(raw, v);
-                    if (c < 15) load_strip_raw<CH>(row_ptr, c + 1, raw);
-                    if (c == 0) {
-                        sA = __fadd_rn(sA, v[0]);
-                        sA = __fadd_rn(sA, v[1]);
-                        sA = __fadd_rn(sA, v[2]);
-                        xrow[2] = __fdiv_rn(sA, 3.0f);
-                        sA = __fadd_rn(sA, v[3]);
-                        xrow[3] = __fmul_rn(sA, 0.25f);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) lagA[k] = v[k];
-#pragma unroll
-                        for (int k = 4; k < kS; ++k) {
-                            sA = __fadd_rn(sA, v[k]);
-                            sA = __fsub_rn(sA, lagA[k & 3]);
-                            lagA[k & 3] = v[k];
-                            xrow[k] = __fmul_rn(sA, 0.25f);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < kS; ++k) {
-                            sA = __fadd_rn(sA, v[k]);
-                            sA = __fsub_rn(sA, lagA[k & 3]);
-                            lagA[k & 3] = v[k];
-                            xrow[k] = __fmul_rn(sA, 0.25f);
-                        }
-                    }
-                } else {  // steps 512, 513 (box1DFloat phase 4): labels 512 (/3) and 513 (/2)
-                    sA = __fsub_rn(sA, lagA[0]);
-                    xrow[0] = __fdiv_rn(sA, 3.0f);
-                    sA = __fsub_rn(sA, lagA[1]);
-                    xrow[1] = __fmul_rn(sA, 0.5f);
-                }
-            }
-            wave_lds_sync();
-
-            // ---------------- B on tile column c  ||  D on tile column c - 1 ---------------------
-            {
-                const int cd = c - 1;
-                const bool b_on = isB && c >= 0 && c <= 16 && (c > 0 || lane >= 2) && (c < 16 || lane < 2);
-                const int jd = 4 * cd - 1 + jj;
-                const bool d_on = isD && cd >= 0 && cd <= 16 && jd >= 0 && jd <= 63;
-                const int par_in = (t - 1) & 1, par_out = t & 1;
-                Run5 st = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                if (r > 0) {
-                    if (b_on) {
-                        st.sum = mbB[r - 1][par_in][0][lane]; st.l0 = mbB[r - 1][par_in][1][lane];
-                        st.l1 = mbB[r - 1][par_in][2][lane]; st.l2 = mbB[r - 1][par_in][3][lane];
-                        st.l3 = mbB[r - 1][par_in][4][lane];
-                    } else if (d_on) {
-                        st.sum = mbD[r - 1][par_in][0][jj]; st.l0 = mbD[r - 1][par_in][1][jj];
-                        st.l1 = mbD[r - 1][par_in][2][jj]; st.l2 = mbD[r - 1][par_in][3][jj];
-                        st.l3 = mbD[r - 1][par_in][4][jj];
-                    }
-                }
-                float* p = &dummy[r * 64];
-                int stride = 0;
-                if (b_on) {
-                    p = &X[r][0][lane];
-                    stride = kTC + 1;
-                } else if (d_on) {
-                    p = &Z[r][cd & 1][jj][0];
-                    stride = 1;
-                }
-                if (r == 0) {
-                    // label rows 0..7: the filter's start-up (B starts at row 0, D at label row 2)
-                    const int first = d_on ? 2 : 0;
-                    float lg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float x = p[q * stride];
-                        const bool valid = q >= first;
-                        const bool sub = q >= first + 4;
-                        float s2 = __fadd_rn(st.sum, x);
-                        if (sub) s2 = __fsub_rn(s2, lg[q & 3]);
-                        st.sum = valid ? s2 : st.sum;
-                        lg[q & 3] = valid ? x : lg[q & 3];
-                        const float o = (q - first == 2) ? __fdiv_rn(st.sum, 3.0f) : __fmul_rn(st.sum, 0.25f);
-                        if (q - first >= 2) p[q * stride] = o;
-                    }
-                    st.l0 = lg[0]; st.l1 = lg[1]; st.l2 = lg[2]; st.l3 = lg[3];
-                    // label rows 8..63: steady state (same chunk macro as colpass64_steady)
-                    const bool emit = d_on;
-                    const int i0 = -1, j = jd;
-                    float a8[8], b8[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) a8[e] = p[(8 + e) * stride];
-#pragma unroll 1
-                    for (int q0 = 8; q0 < 56; q0 += 16) {  // chunk pairs (8,16) (24,32) (40,48)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) b8[e] = p[(q0 + 8 + e) * stride];
-                        HVD_RUN_CHUNK(a8, q0)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) a8[e] = p[(q0 + 16 + e) * stride];
-                        HVD_RUN_CHUNK(b8, q0 + 8)
-                    }
-                    HVD_RUN_CHUNK(a8, 56)  // a8 holds rows 56..63
-                } else if (r < 8) {
-                    colpass64_steady(p, stride, st, d_on, dst, 8 * r - 1, jd);
-                } else {
-                    // label rows 512, 513: B's phase 4 (subtract only: /3, /2); D's last sample (label 512)
-                    const float x0 = d_on ? p[0] : 0.0f;  // B lanes add nothing (sum + 0 is exact)
-                    st.sum = __fsub_rn(__fadd_rn(st.sum, x0), st.l0);
-                    if (b_on) p[0] = __fdiv_rn(st.sum, 3.0f);
-                    if (d_on) dst[63 * 64 + jd] = __fmul_rn(st.sum, 0.25f);
-                    if (b_on) {
-                        st.sum = __fsub_rn(st.sum, st.l1);
-                        p[stride] = __fmul_rn(st.sum, 0.5f);
-                    }
-                }
-                if (r < 8) {
-                    if (b_on) {
-                        mbB[r][par_out][0][lane] = st.sum; mbB[r][par_out][1][lane] = st.l0;
-                        mbB[r][par_out][2][lane] = st.l1; mbB[r][par_out][3][lane] = st.l2;
-                        mbB[r][par_out][4][lane] = st.l3;
-                    } else if (d_on) {
-                        mbD[r][par_out][0][jj] = st.sum; mbD[r][par_out][1][jj] = st.l0;
-                        mbD[r][par_out][2][jj] = st.l1; mbD[r][par_out][3][jj] = st.l2;
-                        mbD[r][par_out][4][jj] = st.l3;
-                    }
-                }
-            }
-            wave_lds_sync();
-
-            // ---------------- C: rep-2 along the label row -------------------------------------
-            // label column u = 32c + k is filter input index u - 2; ring slot (k + 2) & 3; the output is a
-            // decimation sample iff k is a multiple of 8 (u >= 8): sample column j = u/8 - 1, slot k/8
-            if (c >= 0 && c <= 16 && (r < 8 || lane < 2)) {
-                const float* xrow = &X[r][lane][0];
-                float* z = &Z[r][c & 1][0][lane];
-                if (c == 0) {
-                    const float t0 = xrow[2], t1 = xrow[3], t2 = xrow[4], t3 = xrow[5];
-                    sC = __fadd_rn(__fadd_rn(__fadd_rn(t0, t1), t2), t3);
-                    lagC[0] = t0; lagC[1] = t1; lagC[2] = t2; lagC[3] = t3;
-#pragma unroll
-                    for (int k = 6; k < kTC; ++k) {
-                        const float x = xrow[k];
-                        sC = __fsub_rn(__fadd_rn(sC, x), lagC[(k + 2) & 3]);
-                        lagC[(k + 2) & 3] = x;
-                        if ((k & 7) == 0) z[(k >> 3) * (kTR + 1)] = __fmul_rn(sC, 0.25f);
-                    }
-                } else if (c < 16) {
-#pragma unroll
-                    for (int k = 0; k < kTC; ++k) {
-                        const float x = xrow[k];
-                        sC = __fsub_rn(__fadd_rn(sC, x), lagC[(k + 2) & 3]);
-                        lagC[(k + 2) & 3] = x;
-                        if ((k & 7) == 0) z[(k >> 3) * (kTR + 1)] = __fmul_rn(sC, 0.25f);
-                    }
-                } else {
-                    const float x = xrow[0];  // label column 512: sample column 63
-                    sC = __fsub_rn(__fadd_rn(sC, x), lagC[2]);
-                    z[0] = __fmul_rn(sC, 0.25f);
-                }
-            }
-            __syncthreads();  // mailboxes of this step are complete; also orders Z for the next step's D
-        }
-    }
-}
-#undef HVD_RUN_CHUNK
-#undef HVD_RUN_STEP
 
 // ---------------------------------------------------------------------------
 // k_down512w: the same fused down-sampler with ONE WAVE PER FRAME.
@@ -1536,9 +1213,6 @@ static int jarosz_window(int dim) { return (dim + 2 * 64 - 1) / (2 * 64); }
 // Workspace (floats per frame) the down-sampler needs besides the 64x64 output.
 size_t pdq_downsample_ws_floats(int h, int w) { return 2 * (size_t)h * w + (size_t)64 * h; }
 
-bool g_pdq_down512_strip64 = false;    // with split D: 64-column strips, 1 workgroup/CU
-bool g_pdq_down512_split_d = false;    // A/B switch: pass D as its own kernel (k_down512_d); same speed
-bool g_pdq_down512_systolic = false;  // A/B switch: k_down512s instead of k_down512
 bool g_pdq_fused_down512 = true;  // A/B switch (hvd_debug_set "pdq_fused_down512")
 int g_pdq_down512_wave = 1;       // k_down512w (one wave per frame): 0 never, 1 for batches >= 704 frames, 2 always
 int g_pdq_down512_wave_grid = 0;  // waves in flight; 0 = what is resident at once (rgb: 3 per SIMD, gray: 4)
@@ -1553,7 +1227,7 @@ hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int 
         // 4096 (gray) such waves but only 512 such workgroups; crossover measured at ~700 frames
         // (profiles/r01_down512w_ablation.txt). pdq_down512_wave: 0 never, 1 by batch size (default), 2 always.
         const bool use_wave = g_pdq_down512_wave == 2 || (g_pdq_down512_wave == 1 && n >= 704);
-        if (use_wave && !g_pdq_down512_systolic && !g_pdq_down512_split_d) {
+        if (use_wave) {
             // d_ws is sized for min(n, 1024) frames of the generic path (2.2 MB each) >= 10.9 KB per wave here.
             // resident waves: rgb 12 per CU (168 VGPRs, 13 KB of LDS), gray 16 per CU (10 KB of LDS)
             const int64_t resident = g_pdq_down512_wave_grid > 0 ? g_pdq_down512_wave_grid : 256 * (channels == 3 ? 12 : 16);
@@ -1563,38 +1237,10 @@ hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int 
                 hipLaunchKernelGGL(k_down512w<3>, dim3(gw), dim3(64), 0, s, d_frames, (long long)n, d_out64, d_ws);
             else
                 hipLaunchKernelGGL(k_down512w<1>, dim3(gw), dim3(64), 0, s, d_frames, (long long)n, d_out64, d_ws);
-        } else if (g_pdq_down512_systolic) {
-            const unsigned gs = (unsigned)(n < 256 ? n : 256);  // one workgroup per CU (LDS)
-            if (channels == 3)
-                hipLaunchKernelGGL(k_down512s<3>, dim3(gs), dim3(kNW * 64), 0, s, d_frames, (long long)n, d_out64);
-            else
-                hipLaunchKernelGGL(k_down512s<1>, dim3(gs), dim3(kNW * 64), 0, s, d_frames, (long long)n, d_out64);
-        } else if (g_pdq_down512_split_d) {
-            // d_ws holds the C samples (64 x 512 floats per frame); the workspace is sized for min(n, 1024)
-            // frames of the generic path (>= 17 x that many frames here), so go slab by slab
-            const int64_t slab = 16384;
-            for (int64_t f0 = 0; f0 < n; f0 += slab) {
-                const int64_t m = (n - f0) < slab ? (n - f0) : slab;
-                const uint8_t* src = d_frames + (size_t)f0 * kF * kF * channels;
-                float* o64 = d_out64 + (size_t)f0 * 4096;
-                const unsigned g1 = (unsigned)(m < 512 ? m : 512);
-                if (g_pdq_down512_strip64) {
-                    const unsigned g64 = (unsigned)(m < 256 ? m : 256);  // one workgroup per CU (133 KB of LDS)
-                    if (channels == 3)
-                        hipLaunchKernelGGL((k_down512<3, true, 64>), dim3(g64), dim3(512), 0, s, src, (long long)m, o64, d_ws);
-                    else
-                        hipLaunchKernelGGL((k_down512<1, true, 64>), dim3(g64), dim3(512), 0, s, src, (long long)m, o64, d_ws);
-                } else if (channels == 3)
-                    hipLaunchKernelGGL((k_down512<3, true, 32>), dim3(g1), dim3(512), 0, s, src, (long long)m, o64, d_ws);
-                else
-                    hipLaunchKernelGGL((k_down512<1, true, 32>), dim3(g1), dim3(512), 0, s, src, (long long)m, o64, d_ws);
-                const unsigned g2 = (unsigned)(m < 256 * 16 ? m : 256 * 16);
-                hipLaunchKernelGGL(k_down512_d, dim3(g2), dim3(64), 0, s, (const float*)d_ws, (long long)m, o64);
-            }
         } else if (channels == 3)
-            hipLaunchKernelGGL((k_down512<3, false, 32>), dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64, d_ws);
+            hipLaunchKernelGGL(k_down512<3>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
         else
-            hipLaunchKernelGGL((k_down512<1, false, 32>), dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64, d_ws);
+            hipLaunchKernelGGL(k_down512<1>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
         return hipGetLastError();
     }
     if (jarosz_window(h) > kTW || jarosz_window(w) > kTW) return hipErrorInvalidValue;

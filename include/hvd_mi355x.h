@@ -152,7 +152,6 @@ int hvd_get_pdq_dct_mode(void);
  *   "pdq_fused_down512" 0|1                                (0: generic 4-launch down-sampler)
  *   "pdq_down512_wave" 0|1|2                               (wave-per-frame kernel: never | batches >= 704 | always)
  *   "pdq_down512_wave_grid" n                              (waves in flight; 0 = what is resident at once)
- *   "pdq_down512_systolic", "pdq_down512_split_d", "pdq_down512_strip64" 0|1   (workgroup-kernel variants)
  *   "fp4_code", "mfma_col_chunk_max"                       (FP4-MFMA Hamming kernel)
  * Unknown keys and out-of-range values return HVD_ERR_ARG. */
 int hvd_debug_set(const char* key, int value);

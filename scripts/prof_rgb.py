@@ -1,4 +1,4 @@
-"""Workload for rocprofv3 counter passes on the 512x512 front-end. argv[1]: 0 strip kernel, 1 systolic."""
+"""Workload for rocprofv3 counter passes on the 512x512 front-end. argv[1]: pdq_down512_wave (0 workgroup kernel, 1 by batch size, 2 wave kernel)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -6,7 +6,7 @@ import numpy as np
 import hvd_amd
 from hvd_amd import _lib as L, synth
 lib = L.init(0)
-L.check(lib.hvd_debug_set(b"pdq_down512_systolic", int(sys.argv[1]) if len(sys.argv) > 1 else 0))
+L.check(lib.hvd_debug_set(b"pdq_down512_wave", int(sys.argv[1]) if len(sys.argv) > 1 else 1))
 n = 6144
 base = synth.frames_rgb(16, seed=6)
 fr = np.concatenate([base] * (n // 16))

@@ -1,8 +1,8 @@
 #!/bin/bash
 # rocprofv3 PMC passes for the 512x512 front-end kernels.
-# usage: bash scripts/profile_rgb.sh <tag> <0|1 systolic> [pass names...]   (default: every pass)
+# usage: bash scripts/profile_rgb.sh <tag> <pdq_down512_wave: 0|1|2> [pass names...]   (default: every pass)
 set -u
-TAG=${1:-rgb}; MODE=${2:-0}; shift 2 || true
+TAG=${1:-rgb}; MODE=${2:-1}; shift 2 || true
 WANT=${*:-stats sq1 sq2 sq3 fetch tcc tcp1 tcp2 wr}
 REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
