@@ -261,10 +261,14 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_pdq_hash64_fma(const void* __restrict__ in, long long n,
+__global__ __launch_bounds__(256, 3) void k_pdq_hash64_fma(const void* __restrict__ in, long long n,
                                                         const float* __restrict__ dct, uint8_t* __restrict__ hashes,
                                                         int32_t* __restrict__ quality) {
     __shared__ PdqLds lds;
+    // KIND 0: the wave's frame goes through LDS: four 16-byte loads per lane, issued ONE FRAME AHEAD (16 VGPRs),
+    // instead of 128 byte loads whose latency each wave sat out twice per frame (PMC: 44 % of wave time in
+    // s_waitcnt with 3 waves per SIMD).
+    __shared__ __attribute__((aligned(16))) uint8_t fbytes[KIND == 0 ? kWaves : 1][KIND == 0 ? 4096 : 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g4 = lane >> 4, c16 = lane & 15;
@@ -276,17 +280,37 @@ __global__ __launch_bounds__(256) void k_pdq_hash64_fma(const void* __restrict__
     __syncthreads();
 
     const long long groups = (n + kWaves - 1) / kWaves;
+    uint4 nb0 = make_uint4(0, 0, 0, 0), nb1 = nb0, nb2 = nb0, nb3 = nb0;  // the next frame's bytes, in flight
+    if (KIND == 0) {
+        const long long f0 = (long long)blockIdx.x * kWaves + wave;
+        if ((long long)blockIdx.x < groups && f0 < n) {
+            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + f0 * 4096);
+            nb0 = src[lane]; nb1 = src[64 + lane]; nb2 = src[128 + lane]; nb3 = src[192 + lane];
+        }
+    }
     for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
         const long long f = g * kWaves + wave;
         const bool valid = f < n;  // wave-uniform
         float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
         if (valid) {
+            if (KIND == 0) {
+                uint4* dstb = reinterpret_cast<uint4*>(&fbytes[wave][0]);
+                dstb[lane] = nb0; dstb[64 + lane] = nb1; dstb[128 + lane] = nb2; dstb[192 + lane] = nb3;
+                const long long fn = (g + gridDim.x) * kWaves + wave;
+                if (g + gridDim.x < groups && fn < n) {
+                    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + fn * 4096);
+                    nb0 = src[lane]; nb1 = src[64 + lane]; nb2 = src[128 + lane]; nb3 = src[192 + lane];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             // ---- quality: column `lane` of the frame, as in the strict kernel ---------------------
             {
                 float a[64];
                 if (KIND == 0) {
-                    const uint8_t* src = reinterpret_cast<const uint8_t*>(in) + f * 4096 + lane;
+                    const uint8_t* src = &fbytes[wave][lane];
 #pragma unroll
                     for (int k = 0; k < 64; ++k) a[k] = lds.luma_lut[src[k * 64]];
                 } else {
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(256) void k_pdq_hash64_fma(const void* __restrict__
             for (int nb = 0; nb < 4; ++nb) {
                 float af[16];
                 if (KIND == 0) {
-                    const uint8_t* src = reinterpret_cast<const uint8_t*>(in) + f * 4096 + g4 * 64 + 16 * nb + c16;
+                    const uint8_t* src = &fbytes[wave][g4 * 64 + 16 * nb + c16];
 #pragma unroll
                     for (int ks = 0; ks < 16; ++ks) af[ks] = lds.luma_lut[src[ks * 256]];
                 } else {
