@@ -404,6 +404,25 @@ def main():
     }
     if extra:
         out["kernel_variants"] = extra
+    if world == 1:
+        # the reference-shaped loop -- one Python call per video pair, as db/vptree.py:29-31,737 issues them
+        # (tests/benchmarks/test_benchmark_vpdqpy.py:62-73 has the same shape). 64-frame hashes, 1024 calls.
+        vf, voff, _ = synth.video_hashes(33, seed=1, frames_per_video=64, copy_fraction=0.1)
+        blobs = [vf[voff[v]:voff[v + 1]].tobytes() for v in range(33)]
+        hvd_amd.calculate_distance(blobs[0], blobs[1])
+        t = time.perf_counter()
+        ncall = 0
+        for a_ in range(32):
+            for b_ in range(32):
+                hvd_amd.calculate_distance(blobs[a_], blobs[b_ + 1])
+                ncall += 1
+        per_call = (time.perf_counter() - t) / ncall
+        out["reference_shaped_loop"] = {
+            "what": "calculate_distance(a, b) = fix_vpdq_similarity(matchHashBytes(a, b, 31)) on 64-frame video hashes, "
+                    "one call per pair from Python (the reference's VP-tree call pattern)",
+            "us_per_call": round(per_call * 1e6, 1), "calls": ncall,
+            "frame_comparisons_per_s": float(f"{4096 / per_call:.3g}"),
+            "note": "launch-bound by construction; the batch entry points above replace the loop, not the callee"}
     if frames_out:
         out["frames_hashed"] = frames_out
     if cpu:
