@@ -44,6 +44,8 @@ SIGNATURES = {
                                            C.POINTER(_i64)]),
     "hvd_hasher_create": (_int, [_int, _int, _int, _i64, C.POINTER(_vp)]),
     "hvd_hasher_push": (_int, [_vp, _vp]),
+    "hvd_hasher_acquire": (_int, [_vp, C.POINTER(_vp)]),
+    "hvd_hasher_commit": (_int, [_vp]),
     "hvd_hasher_pending": (_int, [_vp, C.POINTER(_i64)]),
     "hvd_hasher_finish": (_int, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "hvd_hasher_destroy": (_int, [_vp]),
@@ -52,6 +54,7 @@ SIGNATURES = {
     "hvd_dev_memset": (_int, [_vp, _int, _sz]),
     "hvd_memcpy_h2d": (_int, [_vp, _vp, _sz]),
     "hvd_memcpy_d2h": (_int, [_vp, _vp, _sz]),
+    "hvd_memcpy_d2d": (_int, [_vp, _vp, _sz]),
     "hvd_dev_sync": (_int, []),
     "hvd_set_pdq_dct_mode": (_int, [_int]),
     "hvd_get_pdq_dct_mode": (_int, []),
@@ -63,6 +66,12 @@ SIGNATURES = {
     "hvd_dev_expand_fp4": (_int, [_vp, _i64, _vp]),
     "hvd_dev_allpairs_hamming256_mfma": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _i64, _vp, _int]),
     "hvd_dev_cross_hamming256_mfma": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _int, _int, _int, _vp, _i64, _vp]),
+    "hvd_dev_video_of_frames": (_int, [_vp, _i64, _i64, _vp]),
+    "hvd_dev_compact_kept": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "hvd_dev_vpdq_match_videos": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _i64, _vp]),
+    "hvd_dev_vpdq_match_videos_cross": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _int, _int, _int, _vp, _i64,
+                                               _vp]),
+    "hvd_dev_synth_video_frames": (_int, [_vp, _i64, _i64, _int, C.c_uint64, _vp]),
     "hvd_allpairs_tile_geometry": (_int, [_i64, _int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "hvd_timer_start": (_int, []),
     "hvd_timer_stop": (_int, [C.POINTER(C.c_float)]),

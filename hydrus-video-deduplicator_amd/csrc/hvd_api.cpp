@@ -68,6 +68,18 @@ struct Ctx {
     uint8_t* m_pin = nullptr;
     int32_t m_seq = 0;
     std::mutex m_mu;
+    // grow-only device scratch of the host-buffer entry points and of the video-level reduction: nothing is
+    // allocated or freed per call once the sizes have been seen (h_mu serialises the users)
+    enum Scr {
+        S_DB, S_IMG, S_GRP, S_PAIRS, S_DB2, S_IMG2, S_GRP2, S_VIDQ, S_VIDT, S_OFF, S_SET, S_SET2, S_PKEYS, S_PCNT, S_LIST,
+        S_LISTALL, S_VOUT, S_FRAMES, S_FSCR, S_HASH, S_QUAL, S_COMPACT, S_COUNTERS, S_N
+    };
+    void* scr[S_N] = {};
+    size_t scr_cap[S_N] = {};
+    unsigned long long v_pslots = 0;  // pair map left behind by vmatch_build for vmatch_emit
+    int v_exchange_mode = 0;          // hvd_debug_set("vmatch_exchange"): 0 exchange keys iff world > 1, 1 always, 2 never
+    int v_force_slots_log2 = 0;       // hvd_debug_set("vmatch_slots_log2"): start the tables this small (tests the regrowth)
+    std::recursive_mutex h_mu;
 };
 Ctx g;
 std::mutex g_mu;
@@ -121,6 +133,7 @@ const float* api_dct_device() {
     (void)hipSetDevice(g.device);
     return g.d_dct;
 }
+int api_bind_device() { return need_ready(); }
 }  // namespace hvd
 
 extern "C" {
@@ -168,18 +181,30 @@ int hvd_init(int device) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(HVD_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
                     prop.gcnArchName);
-    HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&g.ev0));
-    HIP_TRY(hipEventCreate(&g.ev1));
-    fill_dct(g.h_dct);
-    HIP_TRY(hipMalloc((void**)&g.d_dct, sizeof g.h_dct));
-    HIP_TRY(hipMemcpy(g.d_dct, g.h_dct, sizeof g.h_dct, hipMemcpyHostToDevice));
-    if (const char* m = getenv("HVD_PDQ_DCT_MODE")) {  // same switch as hvd_set_pdq_dct_mode()
-        if (!strcmp(m, "fma") || !strcmp(m, "1")) hvd::g_pdq_dct_mode = HVD_DCT_FMA;
-        else if (!strcmp(m, "strict") || !strcmp(m, "0") || !*m) hvd::g_pdq_dct_mode = HVD_DCT_STRICT;
+    int dct_mode = hvd::g_pdq_dct_mode;
+    if (const char* m = getenv("HVD_PDQ_DCT_MODE")) {  // same switch as hvd_set_pdq_dct_mode(); checked before any resource exists
+        if (!strcmp(m, "fma") || !strcmp(m, "1")) dct_mode = HVD_DCT_FMA;
+        else if (!strcmp(m, "strict") || !strcmp(m, "0") || !*m) dct_mode = HVD_DCT_STRICT;
         else return fail(HVD_ERR_ARG, "HVD_PDQ_DCT_MODE=%s: expected strict or fma", m);
     }
+    HIP_TRY(hipSetDevice(device));
+    fill_dct(g.h_dct);
+    hipError_t e = hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&g.ev0);
+    if (e == hipSuccess) e = hipEventCreate(&g.ev1);
+    if (e == hipSuccess) e = hipMalloc((void**)&g.d_dct, sizeof g.h_dct);
+    if (e == hipSuccess) e = hipMemcpy(g.d_dct, g.h_dct, sizeof g.h_dct, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {  // a failed init leaves nothing behind, so that a retry does not leak
+        if (g.d_dct) (void)hipFree(g.d_dct);
+        if (g.ev1) (void)hipEventDestroy(g.ev1);
+        if (g.ev0) (void)hipEventDestroy(g.ev0);
+        if (g.stream) (void)hipStreamDestroy(g.stream);
+        g.d_dct = nullptr;
+        g.ev0 = g.ev1 = nullptr;
+        g.stream = nullptr;
+        return fail(HVD_ERR_HIP, "hvd_init(%d): %s", device, hipGetErrorString(e));
+    }
+    hvd::g_pdq_dct_mode = dct_mode;
     g.device = device;
     g.ready = true;
     return HVD_OK;
@@ -200,6 +225,8 @@ int hvd_shutdown(void) {
     (void)hipStreamDestroy(g.stream);
     for (void** p : {&g.m_a, &g.m_b, &g.m_f, &g.m_o})
         if (*p) (void)hipFree(*p);
+    for (void* p : g.scr)
+        if (p) (void)hipFree(p);
     if (g.m_pin) (void)hipHostFree(g.m_pin);
     g.~Ctx();
     new (&g) Ctx();
@@ -238,6 +265,12 @@ int hvd_memcpy_d2h(void* dst, const void* d_src, size_t bytes) {
     if (int rc = need_ready()) return rc;
     HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
+    return HVD_OK;
+}
+
+int hvd_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
+    if (int rc = need_ready()) return rc;
+    if (bytes) HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, g.stream));
     return HVD_OK;
 }
 
@@ -298,6 +331,16 @@ int hvd_debug_set(const char* key, int value) {
     if (strcmp(key, "pdq_down512_wave_grid") == 0) {
         if (value < 0) return fail(HVD_ERR_ARG, "pdq_down512_wave_grid must not be negative (0 = default)");
         hvd::g_pdq_down512_wave_grid = value;
+        return HVD_OK;
+    }
+    if (strcmp(key, "vmatch_slots_log2") == 0) {
+        if (value != 0 && (value < 4 || value > 30)) return fail(HVD_ERR_ARG, "vmatch_slots_log2: 0 (automatic) or 4..30");
+        g.v_force_slots_log2 = value;
+        return HVD_OK;
+    }
+    if (strcmp(key, "vmatch_exchange") == 0) {
+        if (value < 0 || value > 2) return fail(HVD_ERR_ARG, "vmatch_exchange: 0 iff world > 1, 1 always, 2 never (partial results)");
+        g.v_exchange_mode = value;
         return HVD_OK;
     }
     if (strcmp(key, "pdq_fused_down512") == 0) {
@@ -467,34 +510,44 @@ int hvd_dev_cross_hamming256_mfma(const void* d_img_q, int64_t nq, const void* d
 
 /* ------------------------------------------------- host-buffer entry points -- */
 
+static int scratch(Ctx::Scr id, size_t need, void** out) {
+    if (int rc = grow(&g.scr[id], &g.scr_cap[id], need ? need : 1)) return rc;
+    *out = g.scr[id];
+    return HVD_OK;
+}
+#define SCR(id, bytes, ptr) \
+    do {                    \
+        if (int rc_ = scratch(Ctx::id, (bytes), (void**)&(ptr))) return rc_; \
+    } while (0)
+
 static int hash_frames_host(const uint8_t* frames, int64_t n, int h, int w, int channels, uint8_t* out_hashes,
                             int32_t* out_quality) {
     if (int rc = need_ready()) return rc;
     if (n < 0 || h < 64 || w < 64) return fail(HVD_ERR_ARG, "bad frame geometry n=%lld h=%d w=%d", (long long)n, h, w);
     if (n == 0) return HVD_OK;
     if (!frames || !out_hashes || !out_quality) return fail(HVD_ERR_ARG, "NULL buffer");
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
     const size_t frame_bytes = (size_t)h * w * channels;
     // Batches bound the staging footprint (<= ~1 GiB of frames per batch).
     int64_t batch = (int64_t)((1ull << 30) / frame_bytes);
     if (batch < 1) batch = 1;
     if (batch > n) batch = n;
     const bool need_scratch = !(h == 64 && w == 64 && channels == 1);
-    DevBuf d_in, d_scr, d_h, d_q;
-    HIP_TRY(d_in.alloc(frame_bytes * batch));
+    void *d_in = nullptr, *d_scr = nullptr, *d_h = nullptr, *d_q = nullptr;
+    SCR(S_FRAMES, frame_bytes * batch, d_in);
     if (need_scratch) {
         size_t sb = 0;
         if (int rc = hvd_pdq_scratch_bytes(batch, h, w, channels, &sb)) return rc;
-        HIP_TRY(d_scr.alloc(sb));
+        SCR(S_FSCR, sb, d_scr);
     }
-    HIP_TRY(d_h.alloc(32 * (size_t)batch));
-    HIP_TRY(d_q.alloc(4 * (size_t)batch));
+    SCR(S_HASH, 32 * (size_t)batch, d_h);
+    SCR(S_QUAL, 4 * (size_t)batch, d_q);
     for (int64_t f0 = 0; f0 < n; f0 += batch) {
         const int64_t m = std::min(batch, n - f0);
-        HIP_TRY(hipMemcpyAsync(d_in.p, frames + frame_bytes * f0, frame_bytes * m, hipMemcpyHostToDevice, g.stream));
-        if (int rc = hvd_dev_pdq_hash_frames(d_in.p, m, h, w, channels, need_scratch ? d_scr.p : nullptr, d_h.p, d_q.p))
-            return rc;
-        HIP_TRY(hipMemcpyAsync(out_hashes + 32 * f0, d_h.p, 32 * (size_t)m, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipMemcpyAsync(out_quality + f0, d_q.p, 4 * (size_t)m, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(d_in, frames + frame_bytes * f0, frame_bytes * m, hipMemcpyHostToDevice, g.stream));
+        if (int rc = hvd_dev_pdq_hash_frames(d_in, m, h, w, channels, need_scratch ? d_scr : nullptr, d_h, d_q)) return rc;
+        HIP_TRY(hipMemcpyAsync(out_hashes + 32 * f0, d_h, 32 * (size_t)m, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(out_quality + f0, d_q, 4 * (size_t)m, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
     }
     return HVD_OK;
@@ -511,34 +564,35 @@ int hvd_pdq_hash_frames_rgb24_u8(const uint8_t* frames, int64_t n, int h, int w,
 }
 
 // Runs the default all-pairs kernel (FP4-MFMA form) on a host DB; fetches up to `cap`
-// unordered records.
+// unordered records. Device buffers come from the grow-only pool (caller holds h_mu).
 static int allpairs_host_raw(const uint8_t* db, int64_t n, const int32_t* group, int max_dist,
                              std::vector<hvd_pair>& recs, int64_t cap, int64_t* out_count) {
-    DevBuf d_db, d_img, d_grp, d_pairs, d_cnt;
-    HIP_TRY(d_db.alloc(32 * (size_t)n));
-    HIP_TRY(hipMemcpyAsync(d_db.p, db, 32 * (size_t)n, hipMemcpyHostToDevice, g.stream));
+    void *d_db = nullptr, *d_img = nullptr, *d_grp = nullptr, *d_pairs = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    SCR(S_DB, 32 * (size_t)n, d_db);
+    HIP_TRY(hipMemcpyAsync(d_db, db, 32 * (size_t)n, hipMemcpyHostToDevice, g.stream));
     size_t img_bytes = 0;
     if (int rc = hvd_fp4_image_bytes(n, &img_bytes)) return rc;
-    HIP_TRY(d_img.alloc(img_bytes));
-    if (int rc = hvd_dev_expand_fp4(d_db.p, n, d_img.p)) return rc;
+    SCR(S_IMG, img_bytes, d_img);
+    if (int rc = hvd_dev_expand_fp4(d_db, n, d_img)) return rc;
     if (group) {
-        HIP_TRY(d_grp.alloc(4 * (size_t)n));
-        HIP_TRY(hipMemcpyAsync(d_grp.p, group, 4 * (size_t)n, hipMemcpyHostToDevice, g.stream));
+        SCR(S_GRP, 4 * (size_t)n, d_grp);
+        HIP_TRY(hipMemcpyAsync(d_grp, group, 4 * (size_t)n, hipMemcpyHostToDevice, g.stream));
     }
-    HIP_TRY(d_pairs.alloc(sizeof(hvd_pair) * (size_t)cap));
-    HIP_TRY(d_cnt.alloc(8));
-    HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 8, g.stream));
-    if (int rc = hvd_dev_allpairs_hamming256_mfma(d_db.p, d_img.p, n, group ? d_grp.p : nullptr, max_dist, 0, 1,
-                                                  d_pairs.p, cap, d_cnt.p, HVD_DEFAULT_VARIANT))
+    SCR(S_PAIRS, sizeof(hvd_pair) * (size_t)cap, d_pairs);
+    SCR(S_COUNTERS, 64, d_cnt);
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, g.stream));
+    if (int rc = hvd_dev_allpairs_hamming256_mfma(d_db, d_img, n, group ? d_grp : nullptr, max_dist, 0, 1, d_pairs, cap,
+                                                  d_cnt, HVD_DEFAULT_VARIANT))
         return rc;
     unsigned long long cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     *out_count = (int64_t)cnt;
     const size_t m = (size_t)std::min<unsigned long long>(cnt, (unsigned long long)cap);
     recs.resize(m);
     if (m) {
-        HIP_TRY(hipMemcpyAsync(recs.data(), d_pairs.p, sizeof(hvd_pair) * m, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemcpyAsync(recs.data(), d_pairs, sizeof(hvd_pair) * m, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
     }
     return HVD_OK;
@@ -553,6 +607,7 @@ int hvd_allpairs_hamming256(const uint8_t* db, int64_t n, const int32_t* group, 
     *out_count = 0;
     if (n < 2) return HVD_OK;
     if (!db) return fail(HVD_ERR_ARG, "db is NULL");
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
     std::vector<hvd_pair> recs;
     if (int rc = allpairs_host_raw(db, n, group, max_dist, recs, cap, out_count)) return rc;
     if (*out_count > cap)
@@ -565,6 +620,7 @@ int hvd_allpairs_hamming256(const uint8_t* db, int64_t n, const int32_t* group, 
 
 // Frame-level hits -> per video pair (a = video of the row frame, b = video of the column frame):
 // q_hits = distinct row frames, t_hits = distinct column frames. Output sorted by (a, b).
+// Only the popcount route (max_dist >= 128, never used by the reference) still reduces on the host.
 static void aggregate_video_hits(const std::vector<hvd_pair>& recs, const int32_t* vid_row, const int32_t* vid_col,
                                  std::vector<hvd_vmatch>& res) {
     struct Key {
@@ -660,48 +716,241 @@ int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, in
     return HVD_OK;
 }
 
-int hvd_vpdq_match_videos(const uint8_t* frames, const int64_t* offsets, int64_t V, int max_dist, hvd_vmatch* out,
-                          int64_t cap, int64_t* out_count) {
-    if (int rc = need_ready()) return rc;
-    if (V < 0 || !offsets || !out_count || cap < 0 || (cap > 0 && !out)) return fail(HVD_ERR_ARG, "bad arguments");
-    if (max_dist < 0 || max_dist > 256) return fail(HVD_ERR_ARG, "max_dist=%d out of range [0,256]", max_dist);
-    *out_count = 0;
-    if (offsets[0] != 0) return fail(HVD_ERR_ARG, "offsets[0] must be 0");
-    for (int64_t v = 0; v < V; ++v)
-        if (offsets[v + 1] < offsets[v]) return fail(HVD_ERR_ARG, "offsets must be non-decreasing");
-    const int64_t nf = V > 0 ? offsets[V] : 0;
-    if (nf >= (1ll << 32) || V >= (1ll << 31)) return fail(HVD_ERR_ARG, "too many frames/videos");
-    if (nf < 2) return HVD_OK;
-    if (!frames) return fail(HVD_ERR_ARG, "frames is NULL");
-    // frame -> video map; the kernel drops hits inside one video.
-    std::vector<int32_t> vid((size_t)nf);
-    for (int64_t v = 0; v < V; ++v)
-        for (int64_t f = offsets[v]; f < offsets[v + 1]; ++f) vid[(size_t)f] = (int32_t)v;
-    // Frame-level hits; grow the buffer until they fit.
-    std::vector<hvd_pair> recs;
-    int64_t fcap = std::max<int64_t>(1 << 16, nf), fcount = 0;
-    for (;;) {
-        if (int rc = allpairs_host_raw(frames, nf, vid.data(), max_dist, recs, fcap, &fcount)) return rc;
-        if (fcount <= fcap) break;
-        fcap = fcount;
-    }
-    std::vector<hvd_vmatch> res;
-    aggregate_video_hits(recs, vid.data(), vid.data(), res);
-    *out_count = (int64_t)res.size();
-    if ((int64_t)res.size() > cap)
-        return fail(HVD_ERR_OVERFLOW, "video match buffer too small: need %lld, cap %lld", (long long)res.size(),
-                    (long long)cap);
-    if (!res.empty()) memcpy(out, res.data(), sizeof(hvd_vmatch) * res.size());
+/* ------------------------------------------ video-level search on the device (K3) -- */
+
+}  // extern "C"
+
+namespace {
+
+unsigned long long pow2_at_least(unsigned long long x) {
+    unsigned long long p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+struct VmArgs {
+    const void* d_img_q;  // == d_img_t in the symmetric form
+    uint32_t nq;
+    const void* d_img_t;
+    uint32_t nt;
+    bool rect;
+    const int32_t *d_vid_q, *d_vid_t;    // video index of every frame (== each other in the symmetric form)
+    const int32_t *d_excl_q, *d_excl_t;  // rect only: frames with equal values are not compared (nullable)
+    int max_dist;                        // [0,127]
+    int rank, world;
+};
+
+int read_counters(unsigned long long* d_counters, unsigned long long out[4]) {
+    HIP_TRY(hipMemcpyAsync(out, d_counters, 32, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
     return HVD_OK;
 }
 
-static int check_offsets(const int64_t* offsets, int64_t V, int64_t* nf) {
+// All-pairs pass in video mode -> set of (frame, video) keys -> [key exchange between ranks] -> pair map with
+// the vPDQ counters, left in the pool for vmatch_emit. Overflowing tables are rebuilt larger and only the
+// step that overflowed is repeated; the inputs never move.
+int vmatch_build(const VmArgs& v) {
+    const bool exchange = g.v_exchange_mode == 1 || (g.v_exchange_mode == 0 && v.world > 1);
+    if (exchange && (!g.comm_ready || g.world != v.world || g.rank != v.rank))
+        return fail(HVD_ERR_STATE, "rank %d of %d needs hvd_comm_init() with the same rank/world first", v.rank, v.world);
+    unsigned long long* d_counters = nullptr;
+    SCR(S_COUNTERS, 64, d_counters);
+    const unsigned long long frames = (unsigned long long)v.nt + (v.rect ? v.nq : 0u);
+    unsigned long long slots = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * frames));
+    if (g.v_force_slots_log2) slots = 1ull << g.v_force_slots_log2;
+    unsigned long long* d_set = nullptr;
+    unsigned long long c[4] = {0, 0, 0, 0};
+    for (;;) {
+        SCR(S_SET, 8 * slots, d_set);
+        HIP_TRY(hipMemsetAsync(d_set, 0xFF, 8 * slots, g.stream));
+        HIP_TRY(hipMemsetAsync(d_counters, 0, 32, g.stream));
+        hvd::AllPairsArgs a;
+        a.d_db = nullptr;
+        a.n = v.nt;
+        a.d_group = v.rect ? v.d_excl_q : v.d_vid_q;  // symmetric: frames of one video never match each other
+        a.max_dist = (uint32_t)v.max_dist;
+        a.rank = (uint32_t)v.rank;
+        a.world = (uint32_t)v.world;
+        a.d_pairs = nullptr;
+        a.cap = 0;
+        a.d_count = d_counters + 3;
+        a.variant = HVD_DEFAULT_VARIANT;
+        a.col_chunk = 0;
+        a.sink = hvd::VideoSink{d_set, slots - 1, d_counters, v.d_vid_q, v.d_vid_t};
+        hipError_t e = v.rect ? hvd::launch_cross_mfma(a, v.d_img_q, v.nq, v.d_img_t, v.d_excl_t, g.stream)
+                              : hvd::launch_allpairs_mfma(a, v.d_img_t, g.stream);
+        if (e != hipSuccess) return fail(HVD_ERR_HIP, "video-level all-pairs launch: %s", hipGetErrorString(e));
+        if (int rc = read_counters(d_counters, c)) return rc;
+        if (c[0] == 0) break;
+        slots *= 4;  // some insert ran out of probes: larger table, same pass again
+    }
+    const unsigned long long* d_src = d_set;
+    unsigned long long n_src = slots, n_keys = c[1];
+    if (exchange) {
+        // each rank saw only its tiles' hits: all-gather the key lists and de-duplicate (a key may be found twice)
+        unsigned long long *d_list = nullptr, *d_all = nullptr, *d_set2 = nullptr;
+        const int W = g.world;
+        if (!g.x_cnt_in) HIP_TRY(hipMalloc(&g.x_cnt_in, 8));
+        if (!g.x_cnt_all) HIP_TRY(hipMalloc(&g.x_cnt_all, 8 * (size_t)W));
+        HIP_TRY(hipMemcpyAsync(g.x_cnt_in, &n_keys, 8, hipMemcpyHostToDevice, g.stream));
+        NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 1, ncclUint64, g.comm, g.stream));
+        std::vector<unsigned long long> counts((size_t)W);
+        HIP_TRY(hipMemcpyAsync(counts.data(), g.x_cnt_all, 8 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        unsigned long long mx = 1, total = 0;
+        for (unsigned long long x : counts) {
+            mx = std::max(mx, x);
+            total += x;
+        }
+        SCR(S_LIST, 8 * mx, d_list);  // this rank's keys, padded with empty keys to the longest list
+        HIP_TRY(hipMemsetAsync(d_list, 0xFF, 8 * mx, g.stream));
+        HIP_TRY(hipMemsetAsync(d_counters + 2, 0, 8, g.stream));
+        HIP_TRY(hvd::launch_set_to_list(d_set, slots, d_list, mx, d_counters + 2, g.stream));
+        SCR(S_LISTALL, 8 * mx * (size_t)W, d_all);
+        NCCL_TRY(ncclAllGather(d_list, d_all, 8 * mx, ncclUint8, g.comm, g.stream));
+        unsigned long long slots2 = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * total));
+        if (g.v_force_slots_log2) slots2 = 1ull << g.v_force_slots_log2;
+        for (;;) {
+            SCR(S_SET2, 8 * slots2, d_set2);
+            HIP_TRY(hipMemsetAsync(d_set2, 0xFF, 8 * slots2, g.stream));
+            HIP_TRY(hipMemsetAsync(d_counters, 0, 32, g.stream));
+            HIP_TRY(hvd::launch_list_to_set(d_all, mx * (unsigned long long)W, d_set2, slots2 - 1, d_counters, g.stream));
+            if (int rc = read_counters(d_counters, c)) return rc;
+            if (c[0] == 0) break;
+            slots2 *= 4;
+        }
+        d_src = d_set2;
+        n_src = slots2;
+        n_keys = c[1];
+    }
+    unsigned long long pslots = pow2_at_least(std::max<unsigned long long>(1024, 4ull * n_keys));
+    if (g.v_force_slots_log2) pslots = 1ull << g.v_force_slots_log2;
+    for (;;) {
+        unsigned long long* d_pkeys = nullptr;
+        void* d_pcnt = nullptr;
+        SCR(S_PKEYS, 8 * pslots, d_pkeys);
+        SCR(S_PCNT, 8 * pslots, d_pcnt);
+        HIP_TRY(hipMemsetAsync(d_pkeys, 0xFF, 8 * pslots, g.stream));
+        HIP_TRY(hipMemsetAsync(d_pcnt, 0, 8 * pslots, g.stream));
+        HIP_TRY(hipMemsetAsync(d_counters, 0, 32, g.stream));
+        HIP_TRY(hvd::launch_keys_to_pairs(d_src, n_src, v.d_vid_q, v.d_vid_t, v.rect, d_pkeys, d_pcnt, pslots - 1, d_counters,
+                                          g.stream));
+        if (int rc = read_counters(d_counters, c)) return rc;
+        if (c[0] == 0) break;
+        pslots *= 4;
+    }
+    g.v_pslots = pslots;
+    return HVD_OK;
+}
+
+// Pair map -> hvd_vmatch records (unordered) in d_out[cap]; *d_count (device uint64) = number of video pairs.
+int vmatch_emit(hvd_vmatch* d_out, int64_t cap, unsigned long long* d_count) {
+    HIP_TRY(hipMemsetAsync(d_count, 0, 8, g.stream));
+    HIP_TRY(hvd::launch_pairs_emit((const unsigned long long*)g.scr[Ctx::S_PKEYS], g.scr[Ctx::S_PCNT], g.v_pslots, d_out,
+                                   (unsigned long long)cap, d_count, g.stream));
+    return HVD_OK;
+}
+
+bool vmatch_less(const hvd_vmatch& x, const hvd_vmatch& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; }
+
+// build + emit into the pool's record buffer, grown until everything fits (only the emit is repeated)
+int vmatch_to_host(const VmArgs& v, int64_t expect, std::vector<hvd_vmatch>& res) {
+    if (int rc = vmatch_build(v)) return rc;
+    unsigned long long* d_counters = nullptr;
+    SCR(S_COUNTERS, 64, d_counters);
+    int64_t dcap = std::max<int64_t>(1 << 12, expect);
+    for (;;) {
+        hvd_vmatch* d_out = nullptr;
+        SCR(S_VOUT, sizeof(hvd_vmatch) * (size_t)dcap, d_out);
+        if (int rc = vmatch_emit(d_out, dcap, d_counters + 3)) return rc;
+        unsigned long long cnt = 0;
+        HIP_TRY(hipMemcpyAsync(&cnt, d_counters + 3, 8, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        if ((int64_t)cnt > dcap) {
+            dcap = (int64_t)cnt;
+            continue;
+        }
+        res.resize((size_t)cnt);
+        if (cnt) {
+            HIP_TRY(hipMemcpyAsync(res.data(), d_out, sizeof(hvd_vmatch) * (size_t)cnt, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+        }
+        break;
+    }
+    std::sort(res.begin(), res.end(), vmatch_less);
+    return HVD_OK;
+}
+
+int check_offsets(const int64_t* offsets, int64_t V, int64_t* nf) {
     if (V < 0 || !offsets) return fail(HVD_ERR_ARG, "bad offsets");
     if (offsets[0] != 0) return fail(HVD_ERR_ARG, "offsets[0] must be 0");
     for (int64_t v = 0; v < V; ++v)
         if (offsets[v + 1] < offsets[v]) return fail(HVD_ERR_ARG, "offsets must be non-decreasing");
     *nf = V > 0 ? offsets[V] : 0;
-    if (*nf >= (1ll << 32) || V >= (1ll << 31)) return fail(HVD_ERR_ARG, "too many frames/videos");
+    if (*nf >= (1ll << 32) - 1 || V >= (1ll << 31)) return fail(HVD_ERR_ARG, "too many frames/videos");
+    return HVD_OK;
+}
+
+// upload one side of a host library: frame hashes -> FP4 image, CSR offsets -> frame->video map
+int upload_library(const uint8_t* frames, const int64_t* offsets, int64_t V, int64_t nf, Ctx::Scr s_db, Ctx::Scr s_img,
+                   Ctx::Scr s_vid, void** d_img, int32_t** d_vid) {
+    void* d_db = nullptr;
+    long long* d_off = nullptr;
+    if (int rc = scratch(s_db, 32 * (size_t)nf, &d_db)) return rc;
+    size_t ib = 0;
+    if (int rc = hvd_fp4_image_bytes(nf, &ib)) return rc;
+    if (int rc = scratch(s_img, ib, d_img)) return rc;
+    if (int rc = scratch(s_vid, 4 * (size_t)nf, (void**)d_vid)) return rc;
+    SCR(S_OFF, 8 * (size_t)(V + 1), d_off);
+    HIP_TRY(hipMemcpyAsync(d_db, frames, 32 * (size_t)nf, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(d_off, offsets, 8 * (size_t)(V + 1), hipMemcpyHostToDevice, g.stream));
+    if (int rc = hvd_dev_expand_fp4(d_db, nf, *d_img)) return rc;
+    HIP_TRY(hvd::launch_video_of_frames(d_off, (uint32_t)V, (unsigned long long)nf, *d_vid, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));  // S_OFF is reused by the other side
+    return HVD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hvd_vpdq_match_videos(const uint8_t* frames, const int64_t* offsets, int64_t V, int max_dist, hvd_vmatch* out,
+                          int64_t cap, int64_t* out_count) {
+    if (int rc = need_ready()) return rc;
+    if (!out_count || cap < 0 || (cap > 0 && !out)) return fail(HVD_ERR_ARG, "bad arguments");
+    if (max_dist < 0 || max_dist > 256) return fail(HVD_ERR_ARG, "max_dist=%d out of range [0,256]", max_dist);
+    *out_count = 0;
+    int64_t nf = 0;
+    if (int rc = check_offsets(offsets, V, &nf)) return rc;
+    if (nf < 2) return HVD_OK;
+    if (!frames) return fail(HVD_ERR_ARG, "frames is NULL");
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+    std::vector<hvd_vmatch> res;
+    if (max_dist >= 128) {
+        // popcount route (a tolerance the reference never uses): frame-level hits reduced on the host
+        std::vector<int32_t> vid((size_t)nf);
+        for (int64_t v = 0; v < V; ++v)
+            for (int64_t f = offsets[v]; f < offsets[v + 1]; ++f) vid[(size_t)f] = (int32_t)v;
+        std::vector<hvd_pair> recs;
+        int64_t fcap = std::max<int64_t>(1 << 16, nf), fcount = 0;
+        for (;;) {
+            if (int rc = allpairs_host_raw(frames, nf, vid.data(), max_dist, recs, fcap, &fcount)) return rc;
+            if (fcount <= fcap) break;
+            fcap = fcount;
+        }
+        aggregate_video_hits(recs, vid.data(), vid.data(), res);
+    } else {
+        void* d_img = nullptr;
+        int32_t* d_vid = nullptr;
+        if (int rc = upload_library(frames, offsets, V, nf, Ctx::S_DB, Ctx::S_IMG, Ctx::S_VIDQ, &d_img, &d_vid)) return rc;
+        VmArgs v{d_img, (uint32_t)nf, d_img, (uint32_t)nf, false, d_vid, d_vid, nullptr, nullptr, max_dist, 0, 1};
+        if (int rc = vmatch_to_host(v, V, res)) return rc;
+    }
+    *out_count = (int64_t)res.size();
+    if ((int64_t)res.size() > cap)
+        return fail(HVD_ERR_OVERFLOW, "video match buffer too small: need %lld, cap %lld", (long long)res.size(),
+                    (long long)cap);
+    if (!res.empty()) memcpy(out, res.data(), sizeof(hvd_vmatch) * res.size());
     return HVD_OK;
 }
 
@@ -718,70 +967,122 @@ int hvd_vpdq_match_videos_cross(const uint8_t* frames_q, const int64_t* offsets_
     if (int rc = check_offsets(offsets_t, VT, &nt)) return rc;
     if (nq == 0 || nt == 0) return HVD_OK;
     if (!frames_q || !frames_t) return fail(HVD_ERR_ARG, "frames is NULL");
-    std::vector<int32_t> vq((size_t)nq), vt((size_t)nt), gq, gt;
-    for (int64_t v = 0; v < VQ; ++v)
-        for (int64_t f = offsets_q[v]; f < offsets_q[v + 1]; ++f) vq[(size_t)f] = (int32_t)v;
-    for (int64_t v = 0; v < VT; ++v)
-        for (int64_t f = offsets_t[v]; f < offsets_t[v + 1]; ++f) vt[(size_t)f] = (int32_t)v;
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+    void *d_iq = nullptr, *d_it = nullptr;
+    int32_t *d_vq = nullptr, *d_vt = nullptr, *d_gq = nullptr, *d_gt = nullptr;
+    if (int rc = upload_library(frames_q, offsets_q, VQ, nq, Ctx::S_DB, Ctx::S_IMG, Ctx::S_VIDQ, &d_iq, &d_vq)) return rc;
+    if (int rc = upload_library(frames_t, offsets_t, VT, nt, Ctx::S_DB2, Ctx::S_IMG2, Ctx::S_VIDT, &d_it, &d_vt)) return rc;
     if (ids_q) {  // frames of videos with equal ids are not compared (a query that is also in the target set)
-        gq.resize((size_t)nq);
-        gt.resize((size_t)nt);
-        for (int64_t f = 0; f < nq; ++f) gq[(size_t)f] = ids_q[vq[(size_t)f]];
-        for (int64_t f = 0; f < nt; ++f) gt[(size_t)f] = ids_t[vt[(size_t)f]];
+        std::vector<int32_t> gq((size_t)nq), gt((size_t)nt);
+        for (int64_t v = 0; v < VQ; ++v)
+            for (int64_t f = offsets_q[v]; f < offsets_q[v + 1]; ++f) gq[(size_t)f] = ids_q[v];
+        for (int64_t v = 0; v < VT; ++v)
+            for (int64_t f = offsets_t[v]; f < offsets_t[v + 1]; ++f) gt[(size_t)f] = ids_t[v];
+        SCR(S_GRP, 4 * (size_t)nq, d_gq);
+        SCR(S_GRP2, 4 * (size_t)nt, d_gt);
+        HIP_TRY(hipMemcpyAsync(d_gq, gq.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipMemcpyAsync(d_gt, gt.data(), 4 * (size_t)nt, hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));  // gq/gt are stack-scoped
     }
-    DevBuf d_q, d_t, d_iq, d_it, d_gq, d_gt, d_pairs, d_cnt;
-    size_t bq = 0, bt = 0;
-    if (int rc = hvd_fp4_image_bytes(nq, &bq)) return rc;
-    if (int rc = hvd_fp4_image_bytes(nt, &bt)) return rc;
-    HIP_TRY(d_q.alloc(32 * (size_t)nq));
-    HIP_TRY(d_t.alloc(32 * (size_t)nt));
-    HIP_TRY(d_iq.alloc(bq));
-    HIP_TRY(d_it.alloc(bt));
-    HIP_TRY(hipMemcpyAsync(d_q.p, frames_q, 32 * (size_t)nq, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(d_t.p, frames_t, 32 * (size_t)nt, hipMemcpyHostToDevice, g.stream));
-    if (int rc = hvd_dev_expand_fp4(d_q.p, nq, d_iq.p)) return rc;
-    if (int rc = hvd_dev_expand_fp4(d_t.p, nt, d_it.p)) return rc;
-    if (ids_q) {
-        HIP_TRY(d_gq.alloc(4 * (size_t)nq));
-        HIP_TRY(d_gt.alloc(4 * (size_t)nt));
-        HIP_TRY(hipMemcpyAsync(d_gq.p, gq.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(d_gt.p, gt.data(), 4 * (size_t)nt, hipMemcpyHostToDevice, g.stream));
-    }
-    HIP_TRY(d_cnt.alloc(8));
-    std::vector<hvd_pair> recs;
-    int64_t fcap = std::max<int64_t>(1 << 16, nq);
-    for (;;) {
-        if (d_pairs.p) {
-            HIP_TRY(hipFree(d_pairs.p));
-            d_pairs.p = nullptr;
-        }
-        HIP_TRY(d_pairs.alloc(sizeof(hvd_pair) * (size_t)fcap));
-        HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 8, g.stream));
-        if (int rc = hvd_dev_cross_hamming256_mfma(d_iq.p, nq, d_it.p, nt, ids_q ? d_gq.p : nullptr,
-                                                   ids_q ? d_gt.p : nullptr, max_dist, 0, 1, d_pairs.p, fcap, d_cnt.p))
-            return rc;
-        unsigned long long cnt = 0;
-        HIP_TRY(hipMemcpyAsync(&cnt, d_cnt.p, 8, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        if ((int64_t)cnt > fcap) {
-            fcap = (int64_t)cnt;
-            continue;
-        }
-        recs.resize((size_t)cnt);
-        if (cnt) {
-            HIP_TRY(hipMemcpyAsync(recs.data(), d_pairs.p, sizeof(hvd_pair) * (size_t)cnt, hipMemcpyDeviceToHost,
-                                   g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
-        }
-        break;
-    }
+    VmArgs v{d_iq, (uint32_t)nq, d_it, (uint32_t)nt, true, d_vq, d_vt, d_gq, d_gt, max_dist, 0, 1};
     std::vector<hvd_vmatch> res;
-    aggregate_video_hits(recs, vq.data(), vt.data(), res);
+    if (int rc = vmatch_to_host(v, VQ, res)) return rc;
     *out_count = (int64_t)res.size();
     if ((int64_t)res.size() > cap)
         return fail(HVD_ERR_OVERFLOW, "video match buffer too small: need %lld, cap %lld", (long long)res.size(),
                     (long long)cap);
     if (!res.empty()) memcpy(out, res.data(), sizeof(hvd_vmatch) * res.size());
+    return HVD_OK;
+}
+
+/* ---- device-resident forms: hashes / images / maps already in HBM (BASELINE config 5) ---- */
+
+int hvd_dev_video_of_frames(const void* d_offsets, int64_t V, int64_t n, void* d_out_video) {
+    if (int rc = need_ready()) return rc;
+    if (V < 0 || n < 0 || V >= (1ll << 31) || n >= (1ll << 32) - 1 || !d_offsets || (n > 0 && !d_out_video))
+        return fail(HVD_ERR_ARG, "bad arguments");
+    HIP_TRY(hvd::launch_video_of_frames((const long long*)d_offsets, (uint32_t)V, (unsigned long long)n, (int32_t*)d_out_video,
+                                        g.stream));
+    return HVD_OK;
+}
+
+int hvd_dev_compact_kept(const void* d_hashes, const void* d_quality, int64_t n, const void* d_offsets, int64_t V,
+                         int min_quality, void* d_out_hashes, void* d_out_offsets, void* d_out_video, int64_t* out_kept) {
+    if (int rc = need_ready()) return rc;
+    if (n < 0 || V < 0 || n >= (1ll << 32) - 1 || V >= (1ll << 31) || !d_offsets || !d_out_offsets || !out_kept)
+        return fail(HVD_ERR_ARG, "bad arguments");
+    if (n > 0 && (!d_hashes || !d_quality || !d_out_hashes || !d_out_video)) return fail(HVD_ERR_ARG, "NULL device pointer");
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+    void* d_scr = nullptr;
+    unsigned long long* d_counters = nullptr;
+    SCR(S_COMPACT, hvd::compact_scratch_bytes((unsigned long long)n), d_scr);
+    SCR(S_COUNTERS, 64, d_counters);
+    HIP_TRY(hvd::launch_compact_kept(d_hashes, (const int32_t*)d_quality, (unsigned long long)n, (const long long*)d_offsets,
+                                     (uint32_t)V, min_quality, d_out_hashes, (long long*)d_out_offsets, (int32_t*)d_out_video,
+                                     d_scr, d_counters + 2, g.stream));
+    unsigned long long kept = 0;
+    HIP_TRY(hipMemcpyAsync(&kept, d_counters + 2, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *out_kept = (int64_t)kept;
+    return HVD_OK;
+}
+
+int hvd_dev_vpdq_match_videos(const void* d_img, int64_t n, const void* d_video, int max_dist, int rank, int world,
+                              void* d_out, int64_t cap, void* d_count) {
+    if (int rc = need_ready()) return rc;
+    if (n < 0 || n >= (1ll << 32) - 1) return fail(HVD_ERR_ARG, "n=%lld out of range", (long long)n);
+    if (max_dist < 0 || max_dist >= 128) return fail(HVD_ERR_ARG, "max_dist=%d out of range [0,127]", max_dist);
+    if (world < 1 || rank < 0 || rank >= world) return fail(HVD_ERR_ARG, "bad rank/world %d/%d", rank, world);
+    if (cap < 0 || !d_count || (cap > 0 && !d_out)) return fail(HVD_ERR_ARG, "bad output buffer");
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+    if (n < 2) {
+        HIP_TRY(hipMemsetAsync(d_count, 0, 8, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return HVD_OK;
+    }
+    if (!d_img || !d_video) return fail(HVD_ERR_ARG, "d_img / d_video is NULL");
+    VmArgs v{d_img, (uint32_t)n, d_img, (uint32_t)n, false, (const int32_t*)d_video, (const int32_t*)d_video, nullptr, nullptr,
+             max_dist, rank, world};
+    if (int rc = vmatch_build(v)) return rc;
+    if (int rc = vmatch_emit((hvd_vmatch*)d_out, cap, (unsigned long long*)d_count)) return rc;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return HVD_OK;
+}
+
+int hvd_dev_vpdq_match_videos_cross(const void* d_img_q, int64_t nq, const void* d_video_q, const void* d_excl_q,
+                                    const void* d_img_t, int64_t nt, const void* d_video_t, const void* d_excl_t,
+                                    int max_dist, int rank, int world, void* d_out, int64_t cap, void* d_count) {
+    if (int rc = need_ready()) return rc;
+    if (nq < 0 || nt < 0 || nq >= (1ll << 32) - 1 || nt >= (1ll << 32) - 1) return fail(HVD_ERR_ARG, "set size out of range");
+    if (max_dist < 0 || max_dist >= 128) return fail(HVD_ERR_ARG, "max_dist=%d out of range [0,127]", max_dist);
+    if (world < 1 || rank < 0 || rank >= world) return fail(HVD_ERR_ARG, "bad rank/world %d/%d", rank, world);
+    if (cap < 0 || !d_count || (cap > 0 && !d_out)) return fail(HVD_ERR_ARG, "bad output buffer");
+    if ((d_excl_q == nullptr) != (d_excl_t == nullptr)) return fail(HVD_ERR_ARG, "pass both exclusion maps or neither");
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+    if (nq == 0 || nt == 0) {
+        HIP_TRY(hipMemsetAsync(d_count, 0, 8, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        return HVD_OK;
+    }
+    if (!d_img_q || !d_img_t || !d_video_q || !d_video_t) return fail(HVD_ERR_ARG, "NULL image / video map");
+    VmArgs v{d_img_q, (uint32_t)nq, d_img_t, (uint32_t)nt, true, (const int32_t*)d_video_q, (const int32_t*)d_video_t,
+             (const int32_t*)d_excl_q, (const int32_t*)d_excl_t, max_dist, rank, world};
+    if (int rc = vmatch_build(v)) return rc;
+    if (int rc = vmatch_emit((hvd_vmatch*)d_out, cap, (unsigned long long*)d_count)) return rc;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return HVD_OK;
+}
+
+int hvd_dev_synth_video_frames(void* d_frames, int64_t v0, int64_t n_videos, int frames_per_video, uint64_t seed,
+                               const void* d_copy_of) {
+    if (int rc = need_ready()) return rc;
+    if (v0 < 0 || n_videos < 0 || frames_per_video < 1 || n_videos * (int64_t)frames_per_video >= (1ll << 31))
+        return fail(HVD_ERR_ARG, "bad synthetic library shape");
+    if (n_videos == 0) return HVD_OK;
+    if (!d_frames) return fail(HVD_ERR_ARG, "d_frames is NULL");
+    HIP_TRY(hvd::launch_synth_frames64((uint8_t*)d_frames, v0, (uint32_t)frames_per_video,
+                                       (unsigned long long)n_videos * (unsigned long long)frames_per_video, seed,
+                                       (const int32_t*)d_copy_of, g.stream));
     return HVD_OK;
 }
 
@@ -820,6 +1121,9 @@ static void free_exchange_buffers() {
 }
 
 int hvd_comm_destroy(void) {
+    std::lock_guard<std::mutex> lk(g_mu);  // same lock as hvd_shutdown, which also tears the communicator down
+    if (!g.ready) return HVD_OK;           // hvd_shutdown already destroyed it
+    if (int rc = need_ready()) return rc;
     if (g.comm_ready) {
         (void)hipStreamSynchronize(g.stream);
         free_exchange_buffers();

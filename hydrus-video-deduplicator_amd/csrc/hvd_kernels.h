@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/hvd_mi355x.h"
+#include "hvd_devhash.h"
 
 namespace hvd {
 
@@ -19,6 +20,7 @@ struct AllPairsArgs {
     unsigned long long* d_count;
     int variant;
     uint32_t col_chunk;      // 0 = pick automatically
+    VideoSink sink = {nullptr, 0, nullptr, nullptr, nullptr};  // FP4-MFMA form only: reduce to video level (K3)
 };
 
 hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s);
@@ -35,6 +37,27 @@ hipError_t launch_allpairs_mfma(const AllPairsArgs& a, const void* d_img, hipStr
 hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
                              const int32_t* d_group_t, hipStream_t s);
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
+
+// Video-level reduction and quality compaction (k_vmatch.hip).
+hipError_t launch_keys_to_pairs(const unsigned long long* d_src, unsigned long long n_src, const int32_t* d_vid_q,
+                                const int32_t* d_vid_t, bool rect, unsigned long long* d_pkeys, void* d_pcnt,
+                                unsigned long long pmask, unsigned long long* d_counters, hipStream_t s);
+hipError_t launch_pairs_emit(const unsigned long long* d_pkeys, const void* d_pcnt, unsigned long long slots, hvd_vmatch* d_out,
+                             unsigned long long cap, unsigned long long* d_count, hipStream_t s);
+hipError_t launch_set_to_list(const unsigned long long* d_tab, unsigned long long slots, unsigned long long* d_list,
+                              unsigned long long cap, unsigned long long* d_count, hipStream_t s);
+hipError_t launch_list_to_set(const unsigned long long* d_list, unsigned long long n, unsigned long long* d_tab,
+                              unsigned long long mask, unsigned long long* d_counters, hipStream_t s);
+size_t compact_scratch_bytes(unsigned long long n);
+hipError_t launch_compact_kept(const void* d_hashes, const int32_t* d_quality, unsigned long long n, const long long* d_offsets,
+                               uint32_t V, int min_q, void* d_out_hashes, long long* d_out_offsets, int32_t* d_out_video,
+                               void* d_scratch, unsigned long long* d_total, hipStream_t s);
+hipError_t launch_video_of_frames(const long long* d_offsets, uint32_t V, unsigned long long n, int32_t* d_out_video,
+                                  hipStream_t s);
+
+// Synthetic 64x64 gray video frames generated in HBM (k_synth.hip; workload generator, not on the hashing path).
+hipError_t launch_synth_frames64(uint8_t* d_out, long long v0, uint32_t frames_per_video, unsigned long long n_frames,
+                                 uint64_t seed, const int32_t* d_copy_of, hipStream_t s);
 
 hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_b, uint32_t nb, uint32_t max_dist,
                             uint32_t* d_tflags, int32_t* d_hits, hipStream_t s);

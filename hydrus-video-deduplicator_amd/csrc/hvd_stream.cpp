@@ -16,6 +16,7 @@
 namespace hvd {
 int api_fail(int code, const char* fmt, ...);     // hvd_api.cpp
 const float* api_dct_device();                    // hvd_api.cpp; nullptr before hvd_init
+int api_bind_device();                            // hvd_api.cpp: hipSetDevice(bound device) for the calling thread
 size_t api_scratch_bytes(int64_t n, int h, int w, int channels);
 hipError_t api_launch_hash(const void* d_frames, int64_t n, int h, int w, int channels, void* d_scratch, void* d_hashes,
                            void* d_quality, hipStream_t s);
@@ -49,7 +50,7 @@ struct hvd_hasher {
     int cur = 0;
     std::vector<uint8_t> hashes;   // collected results, frame order
     std::vector<int32_t> quality;
-    bool failed = false;
+    bool acquired = false;         // hvd_hasher_acquire handed out the next frame's slot memory
 };
 
 #define S_TRY(expr)                                                                                        \
@@ -84,6 +85,7 @@ extern "C" {
 
 int hvd_hasher_destroy(hvd_hasher* hs) {
     if (!hs) return HVD_OK;
+    (void)hvd::api_bind_device();
     for (Slot& s : hs->slot) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.h_frames) (void)hipHostFree(s.h_frames);
@@ -134,15 +136,28 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
     return HVD_OK;
 }
 
-/* Copies one frame (width*height*channels bytes) into the ring. Blocks only when the next
- * slot's previous batch is still being hashed. The caller's buffer is not kept. */
-int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame) {
-    if (!hs || !frame) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/frame");
+/* Zero-copy feed: *out_frame is where the NEXT frame (width*height*channels bytes) belongs, inside the
+ * pinned batch slot, so a decoder can reformat straight into it (the reference makes a Python bytes copy
+ * per frame instead, vpdqpy/vpdqpy.py:118). Blocks only when that slot's previous batch is still being
+ * hashed. The frame counts once hvd_hasher_commit() is called; acquire without commit may be repeated. */
+int hvd_hasher_acquire(hvd_hasher* hs, uint8_t** out_frame) {
+    if (!hs || !out_frame) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/out_frame");
+    if (int rc = hvd::api_bind_device()) return rc;
     Slot& s = hs->slot[hs->cur];
     if (s.filled == 0 && s.in_flight) {  // slot being reused: its previous batch must have landed
         if (int rc = collect(hs, s)) return rc;
     }
-    memcpy(s.h_frames + hs->frame_bytes * (size_t)s.filled, frame, hs->frame_bytes);
+    *out_frame = s.h_frames + hs->frame_bytes * (size_t)s.filled;
+    hs->acquired = true;
+    return HVD_OK;
+}
+
+int hvd_hasher_commit(hvd_hasher* hs) {
+    if (!hs) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher");
+    if (!hs->acquired) return hvd::api_fail(HVD_ERR_STATE, "hvd_hasher_commit() without hvd_hasher_acquire()");
+    if (int rc = hvd::api_bind_device()) return rc;
+    hs->acquired = false;
+    Slot& s = hs->slot[hs->cur];
     if (++s.filled == hs->batch) {
         if (int rc = submit(hs, s)) return rc;
         hs->cur = (hs->cur + 1) % kSlots;
@@ -150,22 +165,37 @@ int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame) {
     return HVD_OK;
 }
 
+/* Copies one frame (width*height*channels bytes) into the ring (acquire + memcpy + commit). The caller's
+ * buffer is not kept. */
+int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame) {
+    if (!hs || !frame) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/frame");
+    uint8_t* dst = nullptr;
+    if (int rc = hvd_hasher_acquire(hs, &dst)) return rc;
+    memcpy(dst, frame, hs->frame_bytes);
+    return hvd_hasher_commit(hs);
+}
+
 /* Flushes the partial batch, waits for everything, returns all hashes / qualities in push
  * order (no quality filtering: that is VideoHasher.finish's policy, vpdqpy.py:119). The hasher
  * is empty afterwards and can be reused for the next video. */
 int hvd_hasher_finish(hvd_hasher* hs, uint8_t* out_hashes, int32_t* out_quality, int64_t cap, int64_t* out_n) {
     if (!hs || !out_n) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/out_n");
-    // Slots were submitted in ring order; collect oldest-first so that results stay in frame order.
+    if (int rc = hvd::api_bind_device()) return rc;
+    hs->acquired = false;
+    // Slots are submitted in ring order, so the oldest batch still in flight sits in the slot that will be
+    // filled next: with nothing staged in the current slot it is the current slot itself (the frame count was
+    // a multiple of the batch size), otherwise push() collected it before staging and the oldest is cur+1.
     Slot& c = hs->slot[hs->cur];
-    const bool partial = c.filled > 0;
-    for (int k = 1; k <= kSlots; ++k) {
-        Slot& s = hs->slot[(hs->cur + k) % kSlots];
-        if (&s == &c && partial) {
-            // the current slot may still hold an older in-flight batch only if filled == 0; here it has
-            // staged frames, so any older batch of it was collected in push()
-            if (int rc = submit(hs, s)) return rc;
+    if (c.filled > 0) {
+        for (int k = 1; k <= kSlots; ++k) {
+            Slot& s = hs->slot[(hs->cur + k) % kSlots];
+            if (&s == &c)
+                if (int rc = submit(hs, s)) return rc;  // the partial batch is the youngest
+            if (int rc = collect(hs, s)) return rc;
         }
-        if (int rc = collect(hs, s)) return rc;
+    } else {
+        for (int k = 0; k < kSlots; ++k)
+            if (int rc = collect(hs, hs->slot[(hs->cur + k) % kSlots])) return rc;
     }
     const int64_t n = (int64_t)hs->quality.size();
     *out_n = n;

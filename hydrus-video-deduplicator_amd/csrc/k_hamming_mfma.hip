@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "hvd_devhash.h"
 #include "hvd_kernels.h"
 
 namespace {
@@ -112,19 +113,41 @@ __device__ __forceinline__ v16f tile_dot(const v4i (&a)[4], const v4i (&b)[4]) {
 
 // Rare path: some pair of this 32-candidate panel may be within tolerance. Recompute every
 // query tile of the wave over all 256 bits (A fragments are re-read from memory so that the
-// loop stays rolled and the fast path's registers stay untouched) and append the hits.
+// loop stays rolled and the fast path's registers stay untouched) and report the hits.
 // rect = false: one set, pairs i<j, group[i] != group[j]. rect = true: query set x target set
 // (row index into the query image, column index into the target image), every (i<nq, j<n) pair.
+//
+// Two sinks. Frame-pair mode (vs.set == nullptr): one hvd_pair per hit. Video mode (K3): a hit (i, j) means
+// "frame i has a match in video(j)" and "frame j has a match in video(i)"; those two facts go into the
+// device set as keys, de-duplicated inside the panel before any atomic is issued: frames are stored in video
+// order, so the 32 columns of a panel and the rows a lane walks both visit videos monotonically -- a row key is
+// issued only by the first hit column of its video (ballot of the row's hits against the panel's video
+// segments), a column key only when the row video changes. A panel in which every pair matches (two copies of
+// one video) costs 2 atomics per row and column instead of 1024 appends.
 template <int TILES>
 __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, const uint4* base, uint32_t sw,
                                              uint32_t wrow0, uint32_t j, uint32_t n, uint32_t h, uint32_t li,
                                              const int32_t* __restrict__ group, float thr_full,
                                              hvd_pair* __restrict__ out, unsigned long long cap,
                                              unsigned long long* __restrict__ count, bool rect, uint32_t nq,
-                                             const int32_t* __restrict__ group_t, float inv_scale2) {
+                                             const int32_t* __restrict__ group_t, float inv_scale2,
+                                             const hvd::VideoSink vs) {
     v4i bf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) bf[s] = as_v4i(base[(2u * s + h) ^ sw]);
+    const bool video = vs.set != nullptr;
+    const int32_t gcol = (group != nullptr && j < n) ? (rect ? group_t[j] : group[j]) : 0;
+    int32_t vcol = -1, last_v = -1;
+    uint32_t lowmask = 0;
+    if (video) {
+        vcol = j < n ? vs.vid_t[j] : -1;
+        const int32_t vprev = __shfl_up(vcol, 1);
+        const unsigned long long seg = __ballot(li == 0u || vcol != vprev);  // first column of each video in the panel
+        const uint32_t segh = h ? (uint32_t)(seg >> 32) : (uint32_t)seg;
+        const uint32_t upto = segh & (0xFFFFFFFFu >> (31u - li));  // bit 0 is always set
+        const uint32_t segstart = 31u - (uint32_t)__clz((int)upto);
+        lowmask = ((1u << li) - 1u) & ~((1u << segstart) - 1u);  // lower columns of my video
+    }
 #pragma unroll 1
     for (int t = 0; t < TILES; ++t) {
         const uint32_t hash = wrow0 + 32u * t + li;
@@ -136,9 +159,22 @@ __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, cons
         for (int r = 0; r < 16; ++r) {
             // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
             const uint32_t i = wrow0 + 32u * t + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h;
-            if (acc[r] >= thr_full && j < n && (rect ? i < nq : i < j)) {
-                if (group == nullptr || group[i] != (rect ? group_t[j] : group[j]))
-                    append_pair_m(out, cap, count, i, j, (uint32_t)(256 - (int)(acc[r] * inv_scale2)) >> 1);
+            bool ok = acc[r] >= thr_full && j < n && (rect ? i < nq : i < j);
+            if (ok && group != nullptr) ok = group[i] != gcol;
+            if (!video) {
+                if (ok) append_pair_m(out, cap, count, i, j, (uint32_t)(256 - (int)(acc[r] * inv_scale2)) >> 1);
+                continue;
+            }
+            const unsigned long long rowhits = __ballot(ok);
+            if (rowhits == 0ull) continue;  // wave-uniform
+            const uint32_t mine = h ? (uint32_t)(rowhits >> 32) : (uint32_t)rowhits;
+            if (ok) {
+                if ((mine & lowmask) == 0u) hvd::sink_insert(vs, hvd::vkey_make(0u, i, (uint32_t)vcol));
+                const int32_t vrow = vs.vid_q[i];
+                if (vrow != last_v) {
+                    hvd::sink_insert(vs, hvd::vkey_make(rect ? 1u : 0u, j, (uint32_t)vrow));
+                    last_v = vrow;
+                }
             }
         }
     }
@@ -169,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
                                                           hvd_pair* __restrict__ out, unsigned long long cap,
                                                           unsigned long long* __restrict__ count,
                                                           const uint4* __restrict__ img_q, uint32_t nq,
-                                                          const int32_t* __restrict__ group_t, float scale2) {
+                                                          const int32_t* __restrict__ group_t, float scale2,
+                                                          const hvd::VideoSink vs) {
     constexpr uint32_t WROWS = 32u * TILES, ROWS = 4u * WROWS;
     constexpr int NB = PREFILTER ? 2 : 4;
     __shared__ uint4 lds0[kSuper * 8], lds1[kSuper * 8];
@@ -233,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
 
             if (__builtin_expect(__any(mm >= thr_bits), 0))
                 panel_slow_path<TILES>(imgq, base, sw, wrow0, jsp + cl, n, h, li, group, thr_full, out, cap, count,
-                                       RECT, nq, group_t, 1.0f / scale2);
+                                       RECT, nq, group_t, 1.0f / scale2, vs);
         }
     };
 
@@ -315,7 +352,7 @@ static hipError_t launch_mfma_t(const AllPairsArgs& a, const void* d_img, hipStr
     dim3 grid((a.n + ROWS - 1) / ROWS, (n_pad + chunk - 1) / chunk);
     hipLaunchKernelGGL((k_allpairs_mfma<T, PF, false>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
                        a.d_group, a.max_dist, chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count,
-                       (const uint4*)nullptr, 0u, (const int32_t*)nullptr, fp4_scale2());
+                       (const uint4*)nullptr, 0u, (const int32_t*)nullptr, fp4_scale2(), a.sink);
     return hipGetLastError();
 }
 
@@ -336,7 +373,7 @@ static hipError_t launch_cross_t(const AllPairsArgs& a, const void* d_img_q, uin
     dim3 grid((unsigned)n_rb, (unsigned)((n_pad + chunk - 1) / chunk));
     hipLaunchKernelGGL((k_allpairs_mfma<T, PF, true>), grid, dim3(256), 0, s, (const uint4*)d_img_t, a.n, n_pad,
                        a.d_group, a.max_dist, (uint32_t)chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count,
-                       (const uint4*)d_img_q, nq, d_group_t, fp4_scale2());
+                       (const uint4*)d_img_q, nq, d_group_t, fp4_scale2(), a.sink);
     return hipGetLastError();
 }
 

@@ -90,6 +90,10 @@ class RcclExchange:
             _lib.check(rc)
             return out[: total.value].copy()
 
+    def allgather_bytes_dev(self, d_send_ptr: int, d_recv_ptr: int, bytes_per_rank: int) -> None:
+        """RCCL all-gather of equally sized device buffers (hash shards produced on-device, config 5)."""
+        _lib.check(_lib.ensure().hvd_comm_allgather_bytes(d_send_ptr, d_recv_ptr, bytes_per_rank))
+
     def close(self) -> None:
         _lib.check(_lib.load().hvd_comm_destroy())
 

@@ -1,13 +1,28 @@
 """Batch pipeline over a whole library: hash every video's frames in one pass over HBM, then
 search all video pairs (BASELINE config 5 shape). The reference does this one video at a time
 (`dedup.py:346-352`) and one tree probe per video (`dedup.py:468-475`); a GPU wants the batch.
+
+Two forms:
+
+* host arrays in, Python objects out (`hash_videos`, `dedupe_videos`) -- convenience, mirrors the
+  per-video API;
+* **device-resident** (`DeviceLibrary`, `dedupe_frames_on_device`): frames already in HBM are hashed,
+  the quality filter (`VideoHasher.finish`, vpdqpy/vpdqpy.py:119: quality >= 31 kept,
+  db/DedupeDB.py:550-553) runs as a stream compaction on the GPU together with the per-video CSR
+  offsets, the kept hashes are rewritten as their FP4 image and searched, and the video-level
+  vPDQ counters are reduced on the GPU. Nothing but `hvd_vmatch` records and the V+1 offsets
+  crosses PCIe. With one process per GPU the frames are hashed in disjoint video ranges and the
+  hash shards are all-gathered over RCCL before the sharded search.
 """
 
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
-from . import search, vpdq
+from . import _lib, search, vpdq
+from ._lib import VMATCH_DTYPE, DeviceBuffer
 
 
 def hash_videos(videos) -> list[vpdq.VpdqHash]:
@@ -39,3 +54,180 @@ def dedupe_videos(videos, threshold: float = 50.0, policy: str | None = None):
     reference would mark as potential duplicates at `threshold` (dedup.py:445-502)."""
     phashes = hash_videos(videos)
     return phashes, search.find_potential_duplicates(phashes, threshold, policy)
+
+
+# ------------------------------------------------------------------ device-resident form ------
+
+
+def hash_frames_on_device(d_frames_ptr: int, n: int, h: int, w: int, channels: int):
+    """PDQ-hash n frames that already sit in HBM -> (d_hashes, d_quality) DeviceBuffers (n*32 B, int32[n]).
+    Enqueued on the library stream; no host synchronisation."""
+    lib = _lib.ensure()
+    d_h = DeviceBuffer(32 * max(n, 1))
+    d_q = DeviceBuffer(4 * max(n, 1))
+    sb = C.c_size_t(0)
+    _lib.check(lib.hvd_pdq_scratch_bytes(n, h, w, channels, C.byref(sb)))
+    d_s = DeviceBuffer(sb.value) if sb.value else None
+    _lib.check(lib.hvd_dev_pdq_hash_frames(d_frames_ptr, n, h, w, channels, d_s.ptr if d_s else None, d_h.ptr, d_q.ptr))
+    if d_s is not None:
+        _lib.check(lib.hvd_dev_sync())  # the scratch must outlive the kernels
+        d_s.free()
+    return d_h, d_q
+
+
+class DeviceLibrary:
+    """A video library resident in HBM: kept frame hashes (CSR by video), their FP4 image and the
+    frame -> video map -- the operand of the video-level search."""
+
+    def __init__(self, d_hashes: DeviceBuffer, d_offsets: DeviceBuffer, d_video: DeviceBuffer, n_frames: int,
+                 n_videos: int):
+        self.d_hashes, self.d_offsets, self.d_video = d_hashes, d_offsets, d_video
+        self.n_frames, self.n_videos = int(n_frames), int(n_videos)
+        self.d_img = None
+        self._lengths = None
+
+    @classmethod
+    def from_raw_hashes(cls, d_hashes_ptr: int, d_quality_ptr: int, n: int, raw_offsets: np.ndarray,
+                        min_quality: int = vpdq.QUALITY_TOLERANCE) -> "DeviceLibrary":
+        """Quality filter + CSR on the device (hvd_dev_compact_kept). raw_offsets: int64[V+1] over the n
+        hashed frames (host array; V+1 numbers are the only thing uploaded)."""
+        lib = _lib.ensure()
+        raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.int64)
+        V = raw_offsets.size - 1
+        if V < 0 or raw_offsets[0] != 0 or raw_offsets[-1] != n or (np.diff(raw_offsets) < 0).any():
+            raise ValueError("raw_offsets must be a CSR over the n frames")
+        d_roff = DeviceBuffer.from_array(raw_offsets)
+        d_out_h = DeviceBuffer(32 * max(n, 1))
+        d_out_off = DeviceBuffer(8 * (V + 1))
+        d_out_vid = DeviceBuffer(4 * max(n, 1))
+        kept = C.c_int64(0)
+        try:
+            _lib.check(lib.hvd_dev_compact_kept(d_hashes_ptr, d_quality_ptr, n, d_roff.ptr, V, int(min_quality),
+                                                d_out_h.ptr, d_out_off.ptr, d_out_vid.ptr, C.byref(kept)))
+        finally:
+            d_roff.free()
+        return cls(d_out_h, d_out_off, d_out_vid, kept.value, V)
+
+    @classmethod
+    def from_host(cls, frames: np.ndarray, offsets: np.ndarray) -> "DeviceLibrary":
+        """Upload an existing library (hashes uint8[sum,32] + CSR offsets)."""
+        lib = _lib.ensure()
+        frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, 32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n, V = frames.shape[0], offsets.size - 1
+        if V < 0 or offsets[-1] != n:
+            raise ValueError("offsets[-1] must equal the number of frame hashes")
+        d_h = DeviceBuffer.from_array(frames) if n else DeviceBuffer(1)
+        d_off = DeviceBuffer.from_array(offsets)
+        d_vid = DeviceBuffer(4 * max(n, 1))
+        _lib.check(lib.hvd_dev_video_of_frames(d_off.ptr, V, n, d_vid.ptr))
+        return cls(d_h, d_off, d_vid, n, V)
+
+    def image(self) -> DeviceBuffer:
+        """FP4 image of the kept hashes (built once, cached)."""
+        if self.d_img is None:
+            lib = _lib.ensure()
+            sz = C.c_size_t(0)
+            _lib.check(lib.hvd_fp4_image_bytes(self.n_frames, C.byref(sz)))
+            self.d_img = DeviceBuffer(sz.value)
+            _lib.check(lib.hvd_dev_expand_fp4(self.d_hashes.ptr, self.n_frames, self.d_img.ptr))
+        return self.d_img
+
+    def offsets(self) -> np.ndarray:
+        return self.d_offsets.to_array(np.int64, self.n_videos + 1)
+
+    def lengths(self) -> np.ndarray:
+        if self._lengths is None:
+            self._lengths = np.diff(self.offsets())
+        return self._lengths
+
+    def hashes(self) -> np.ndarray:
+        return self.d_hashes.to_array(np.uint8, 32 * self.n_frames).reshape(-1, 32)
+
+    def match_videos(self, max_dist: int | None = None, rank: int = 0, world: int = 1, cap: int | None = None) -> np.ndarray:
+        """hvd_dev_vpdq_match_videos: VMATCH_DTYPE records sorted by (a, b); only these cross PCIe."""
+        lib = _lib.ensure()
+        max_dist = vpdq.frame_max_dist(search.DISTANCE_TOLERANCE) if max_dist is None else int(max_dist)
+        if max_dist < 0 or self.n_frames < 2:
+            return np.zeros(0, dtype=VMATCH_DTYPE)
+        cap = max(4096, self.n_videos) if cap is None else int(cap)
+        d_cnt = DeviceBuffer(8)
+        try:
+            while True:
+                d_out = DeviceBuffer(16 * cap)
+                try:
+                    _lib.check(lib.hvd_dev_vpdq_match_videos(self.image().ptr, self.n_frames, self.d_video.ptr, max_dist,
+                                                             rank, world, d_out.ptr, cap, d_cnt.ptr))
+                    cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+                    if cnt <= cap:
+                        recs = d_out.to_array(VMATCH_DTYPE, cnt)
+                        return recs[np.lexsort((recs["b"], recs["a"]))]
+                    cap = cnt
+                finally:
+                    d_out.free()
+        finally:
+            d_cnt.free()
+
+    def free(self) -> None:
+        for b in (self.d_hashes, self.d_offsets, self.d_video, self.d_img):
+            if b is not None:
+                b.free()
+        self.d_img = None
+
+
+def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, w: int, channels: int,
+                            threshold: float = 50.0, policy: str | None = None, rank: int = 0, world: int = 1,
+                            exchange=None, keep_library: bool = False):
+    """BASELINE config 5 for one rank: the frames of videos [v_lo, v_hi) of this rank sit at d_frames_ptr
+    (world == 1: all of them); raw_offsets is the CSR of the WHOLE library. Hash -> (all-gather of the hash
+    shards) -> quality filter + CSR -> FP4 image -> sharded video search with the counters reduced on the GPU
+    -> pair predicate of dedup.py:445-502 on the few video-level records.
+    -> (pairs int64[m,2], records, library or None). Every rank returns the same result."""
+    lib = _lib.ensure()
+    raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.int64)
+    V = raw_offsets.size - 1
+    n_total = int(raw_offsets[-1])
+    v_lo, v_hi = video_range_of_rank(V, rank, world)
+    f_lo, f_hi = int(raw_offsets[v_lo]), int(raw_offsets[v_hi])
+    n_mine = f_hi - f_lo
+    d_h, d_q = hash_frames_on_device(d_frames_ptr, n_mine, h, w, channels)
+    if world > 1:
+        if exchange is None:
+            raise ValueError("world > 1 needs the RCCL exchange")
+        shard = max(int(raw_offsets[video_range_of_rank(V, r, world)[1]] - raw_offsets[video_range_of_rank(V, r, world)[0]])
+                    for r in range(world))
+        d_all_h, d_all_q = DeviceBuffer(32 * shard * world), DeviceBuffer(4 * shard * world)
+        d_ph, d_pq = DeviceBuffer(32 * shard), DeviceBuffer(4 * shard)  # my shard, padded to the longest
+        d_ph.zero()
+        d_pq.zero()
+        _lib.check(lib.hvd_memcpy_d2d(d_ph.ptr, d_h.ptr, 32 * n_mine))
+        _lib.check(lib.hvd_memcpy_d2d(d_pq.ptr, d_q.ptr, 4 * n_mine))
+        exchange.allgather_bytes_dev(d_ph.ptr, d_all_h.ptr, 32 * shard)
+        exchange.allgather_bytes_dev(d_pq.ptr, d_all_q.ptr, 4 * shard)
+        # ranks own contiguous video ranges: squeeze the padding out so that the frames are in library order
+        d_fh, d_fq = DeviceBuffer(32 * max(n_total, 1)), DeviceBuffer(4 * max(n_total, 1))
+        for r in range(world):
+            lo, hi = video_range_of_rank(V, r, world)
+            a, b = int(raw_offsets[lo]), int(raw_offsets[hi])
+            if b > a:
+                _lib.check(lib.hvd_memcpy_d2d(d_fh.ptr + 32 * a, d_all_h.ptr + 32 * shard * r, 32 * (b - a)))
+                _lib.check(lib.hvd_memcpy_d2d(d_fq.ptr + 4 * a, d_all_q.ptr + 4 * shard * r, 4 * (b - a)))
+        for buf in (d_h, d_q, d_all_h, d_all_q, d_ph, d_pq):
+            buf.free()
+        d_h, d_q = d_fh, d_fq
+    library = DeviceLibrary.from_raw_hashes(d_h.ptr, d_q.ptr, n_total, raw_offsets)
+    d_h.free()
+    d_q.free()
+    recs = library.match_videos(rank=rank, world=world)
+    pairs = search.similar_video_pairs(recs, library.lengths(), threshold, policy)
+    if keep_library:
+        return pairs, recs, library
+    library.free()
+    return pairs, recs, None
+
+
+def video_range_of_rank(V: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous share of the videos hashed by `rank` (frames are independent: no collective while hashing)."""
+    per = (V + world - 1) // world
+    lo = min(V, rank * per)
+    return lo, min(V, lo + per)

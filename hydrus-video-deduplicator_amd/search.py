@@ -66,6 +66,8 @@ def match_videos(frames: np.ndarray, offsets: np.ndarray, max_dist: int = DISTAN
     V = offsets.size - 1
     if V < 0 or (V >= 0 and offsets[-1] != frames.shape[0]):
         raise ValueError("offsets[-1] must equal the number of frame hashes")
+    if max_dist < 0:  # comparator "lt" at tolerance 0: nothing can match
+        return np.zeros(0, dtype=VMATCH_DTYPE)
     lib = _lib.ensure()
     cap = max(1024, V) if cap is None else int(cap)
     while True:
@@ -100,6 +102,8 @@ def match_videos_cross(frames_q: np.ndarray, offsets_q: np.ndarray, frames_t: np
         ids_t = np.ascontiguousarray(ids_t, dtype=np.int32)
         if ids_q.shape != (VQ,) or ids_t.shape != (VT,):
             raise ValueError("one id per video")
+    if max_dist < 0:
+        return np.zeros(0, dtype=VMATCH_DTYPE)
     lib = _lib.ensure()
     cap = max(1024, VQ) if cap is None else int(cap)
     while True:
@@ -156,6 +160,6 @@ def find_potential_duplicates(video_hashes, threshold: float = 50.0, policy: str
     offsets = np.zeros(len(blobs) + 1, dtype=np.int64)
     np.cumsum(lengths, out=offsets[1:])
     frames = np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(-1, 32)
-    recs = match_videos(frames, offsets)
+    recs = match_videos(frames, offsets, vpdq.frame_max_dist(DISTANCE_TOLERANCE))
     pairs = similar_video_pairs(recs, lengths, threshold, policy)
     return [(int(a), int(b)) for a, b in pairs]

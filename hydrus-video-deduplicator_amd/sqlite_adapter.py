@@ -99,7 +99,7 @@ def find_potential_duplicates(conn: sqlite3.Connection, threshold: float = 50.0,
 
     # --- GPU: pairs of distinct perceptual hashes with at least one frame hit -----------------
     if phash_pending.all() or phash_pending.sum() * 2 > P:
-        recs = matcher.match_videos(lib.frames, lib.offsets, search.DISTANCE_TOLERANCE)
+        recs = matcher.match_videos(lib.frames, lib.offsets, search.vpdq.frame_max_dist(search.DISTANCE_TOLERANCE))
         a_idx, b_idx = recs["a"].astype(np.int64), recs["b"].astype(np.int64)
     else:
         q_sel = np.flatnonzero(phash_pending)
@@ -109,7 +109,7 @@ def find_potential_duplicates(conn: sqlite3.Connection, threshold: float = 50.0,
             np.zeros((0, 32), np.uint8)
         recs = matcher.match_videos_cross(q_frames, q_off, lib.frames, lib.offsets,
                                           ids_q=q_sel.astype(np.int32), ids_t=np.arange(P, dtype=np.int32),
-                                          max_dist=search.DISTANCE_TOLERANCE)
+                                          max_dist=search.vpdq.frame_max_dist(search.DISTANCE_TOLERANCE))
         a_idx, b_idx = q_sel[recs["a"].astype(np.int64)], recs["b"].astype(np.int64)
     na, nb = lengths[a_idx].astype(np.float64), lengths[b_idx].astype(np.float64)
     with np.errstate(divide="ignore", invalid="ignore"):

@@ -14,10 +14,17 @@ i.e. exactly the five names the reference imports from it:
 All arithmetic runs in HIP kernels on an MI355X through the C-ABI of
 include/hvd_mi355x.h; there is no CPU fallback.
 
-Semantics that the (absent) wheel does not let us pin are explicit policies
-(SURVEY.md 3.5): the comparator is ``hamming <= tolerance`` and the reduction of the two
-vPDQ percentages (query-matched %, target-matched %) to one number is ``MATCH_POLICY``
-(default "min": the only symmetric choice, which dedup.py:502's ``// 2`` assumes).
+Semantics that the (absent) wheel does not let us pin are explicit, tested policies
+(SURVEY.md 3.5), each selectable by an environment variable or at run time:
+
+* ``MATCH_COMPARATOR`` (``HVD_MATCH_COMPARATOR`` = ``le`` | ``lt``): a frame pair is a hit when
+  ``hamming <= tolerance`` (default) or ``hamming < tolerance``. Distances are integers, so ``lt``
+  is ``le`` at ``tolerance - 1``; the kernels always take the inclusive bound (``frame_max_dist``).
+  UNVERIFIED DEFAULT: upstream's matchTwoHashBrute may be strict; tests/golden/import_reference.py
+  settles it where the wheel is installable.
+* ``MATCH_POLICY`` (``HVD_MATCH_POLICY``): reduction of the two vPDQ percentages (query-matched %,
+  target-matched %) to one number; default "min", the only symmetric choice, which
+  dedup.py:502's ``// 2`` assumes.
 """
 
 from __future__ import annotations
@@ -35,6 +42,20 @@ QUALITY_TOLERANCE = 31  # frames with quality >= 31 are kept (db/DedupeDB.py:550
 # "min" | "max" | "query" | "target"; see module docstring.
 MATCH_POLICY = os.environ.get("HVD_MATCH_POLICY", "min")
 _POLICIES = ("min", "max", "query", "target")
+
+# "le" | "lt"; see module docstring.
+MATCH_COMPARATOR = os.environ.get("HVD_MATCH_COMPARATOR", "le")
+_COMPARATORS = ("le", "lt")
+
+
+def frame_max_dist(distance_tolerance, comparator: str | None = None) -> int:
+    """Inclusive Hamming bound the kernels use for a reference-style tolerance under the comparator
+    policy: tolerance for "le", tolerance - 1 for "lt" (-1 = nothing matches)."""
+    comparator = MATCH_COMPARATOR if comparator is None else comparator
+    if comparator not in _COMPARATORS:
+        raise ValueError(f"unknown comparator {comparator!r}; expected one of {_COMPARATORS}")
+    tol = int(distance_tolerance)
+    return tol if comparator == "le" else tol - 1
 
 
 def set_dct_mode(mode: str) -> None:
@@ -152,6 +173,29 @@ class VideoHasher:
         self._handle = h
         self._channels = channels
 
+    def acquire_frame(self, channels: int = 3) -> np.ndarray:
+        """Zero-copy feed (hvd_hasher_acquire): a writable uint8 view of the pinned slot memory for the NEXT
+        frame -- shape (height, width, 3) or (height, width) -- so that a decoder can reformat straight into
+        it (e.g. ``frame.to_ndarray(...)`` with ``out=``, or ``np.copyto``); ``commit_frame()`` makes it count.
+        Blocks like ``hash_frame`` when every batch slot is in flight."""
+        if self._finished:
+            raise RuntimeError("acquire_frame() after finish()")
+        if channels not in (1, 3):
+            raise ValueError("channels must be 1 (gray) or 3 (rgb24)")
+        if self._handle is None:
+            self._open(channels)
+        elif channels != self._channels:
+            raise ValueError("all frames of one video must have the same pixel format")
+        p = C.c_void_p()
+        _lib.check(self._lib.hvd_hasher_acquire(self._handle, C.byref(p)))
+        nbytes = self._frame_bytes_rgb if channels == 3 else self._frame_bytes_gray
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        shape = (self.height, self.width, 3) if channels == 3 else (self.height, self.width)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
+
+    def commit_frame(self) -> None:
+        _lib.check(self._lib.hvd_hasher_commit(self._handle))
+
     def hash_frame(self, frame) -> None:
         """frame: packed RGB24 bytes (width*height*3, what bytes(frame.planes[0]) yields at
         vpdqpy.py:118) or gray bytes (width*height). The buffer is copied before returning."""
@@ -241,7 +285,12 @@ def match_counts(a: bytes, b: bytes, distance_tolerance: int = 31) -> tuple[int,
 
 def matchHashBytes(a: bytes, b: bytes, distance_tolerance: int) -> float:
     """db/vptree.py:31 call shape: similarity in [0,100] from two raw BLOBs."""
-    q, t = match_counts(a, b, distance_tolerance)
+    max_dist = frame_max_dist(distance_tolerance)
+    if max_dist < 0:
+        if len(a) % BYTES_PER_PDQ_HASH or len(b) % BYTES_PER_PDQ_HASH:
+            raise ValueError("hash byte strings must be multiples of 32 bytes")
+        return 0.0
+    q, t = match_counts(a, b, max_dist)
     return percent_from_hits(q, t, len(a) // BYTES_PER_PDQ_HASH, len(b) // BYTES_PER_PDQ_HASH)
 
 

@@ -6,6 +6,7 @@ format ``frame_extract_pyav`` yields: 512x512 packed rgb24 (vpdqpy.py:90-95)."""
 
 from __future__ import annotations
 
+import os
 from collections.abc import Iterable
 
 import numpy as np
@@ -32,6 +33,11 @@ class Vpdq:
         (then width/height default to DOWNSCALE_DIMENSIONS, as the reference passes)."""
         if frames is None:
             raise ValueError
+        if isinstance(frames, (bytes, bytearray, memoryview, str, os.PathLike)):
+            # the reference's caller passes the ENCODED video (dedup.py:76) and decodes it with PyAV; decoding is
+            # out of scope here, and iterating a bytes object would silently hash garbage
+            raise ValueError("encoded video input (bytes / path) is not supported: decode first and pass the frames "
+                             "(uint8[n,h,w,3] array or an iterable of per-frame byte strings)")
         average_fps = 1  # timestamps are discarded (vpdqpy.py:110-112)
         if isinstance(frames, np.ndarray):
             if frames.ndim not in (3, 4):

@@ -39,7 +39,7 @@ extern "C" {
 
 #define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
 #define HVD_UNIQUE_ID_BYTES 128
-#define HVD_ABI_VERSION 1
+#define HVD_ABI_VERSION 2
 #define HVD_DEFAULT_VARIANT 9 /* all-pairs kernel the host entry points use: FP4-MFMA + 128-bit prefilter */
 
 typedef struct {
@@ -119,6 +119,12 @@ int hvd_vpdq_match_videos_cross(const uint8_t* frames_q, const int64_t* offsets_
 typedef struct hvd_hasher hvd_hasher;
 int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames, hvd_hasher** out);
 int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame);
+/* Zero-copy feed: *out_frame is where the next frame (width*height*channels bytes) belongs inside the pinned
+ * batch slot, so a decoder can reformat straight into it instead of handing over a copy (the reference copies
+ * every frame into a Python bytes object, vpdqpy/vpdqpy.py:118); hvd_hasher_commit() makes it count.
+ * acquire blocks like push; push == acquire + memcpy + commit. */
+int hvd_hasher_acquire(hvd_hasher* hs, uint8_t** out_frame);
+int hvd_hasher_commit(hvd_hasher* hs);
 int hvd_hasher_pending(hvd_hasher* hs, int64_t* out_frames);
 /* All hashes (n*32 bytes) and qualities in push order; the hasher is reusable afterwards. */
 int hvd_hasher_finish(hvd_hasher* hs, uint8_t* out_hashes, int32_t* out_quality, int64_t cap, int64_t* out_n);
@@ -134,6 +140,7 @@ int hvd_dev_free(void* d_ptr);
 int hvd_dev_memset(void* d_ptr, int value, size_t bytes);
 int hvd_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int hvd_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
+int hvd_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes); /* enqueued on the library stream */
 int hvd_dev_sync(void);
 
 /* DCT accumulation mode of the frame hash. HVD_DCT_STRICT (default): every `sum += D*A` is a
@@ -153,6 +160,8 @@ int hvd_get_pdq_dct_mode(void);
  *   "pdq_down512_wave" 0|1|2                               (wave-per-frame kernel: never | batches >= 704 | always)
  *   "pdq_down512_wave_grid" n                              (waves in flight; 0 = what is resident at once)
  *   "fp4_code", "mfma_col_chunk_max"                       (FP4-MFMA Hamming kernel)
+ *   "vmatch_exchange" 0|1|2                                (key exchange of the video search: iff world > 1 | always | never)
+ *   "vmatch_slots_log2" 0|4..30                            (initial size of the video-reduction tables; tests the regrowth)
  * Unknown keys and out-of-range values return HVD_ERR_ARG. */
 int hvd_debug_set(const char* key, int value);
 
@@ -187,6 +196,44 @@ int hvd_dev_allpairs_hamming256_mfma(const void* d_db, const void* d_img, int64_
 int hvd_dev_cross_hamming256_mfma(const void* d_img_q, int64_t nq, const void* d_img_t, int64_t nt,
                                   const void* d_group_q, const void* d_group_t, int max_dist, int rank, int world,
                                   void* d_pairs, int64_t cap, void* d_count);
+
+/* ---- video-level search with everything resident in HBM (BASELINE config 5: hash on the GPU, then search) ----
+ * The three calls below use library-owned grow-only scratch, synchronise the library stream before returning
+ * and are serialised against each other. */
+
+/* d_out_video[f] = index of the video that owns frame f, from CSR offsets (int64[V+1] on the device). */
+int hvd_dev_video_of_frames(const void* d_offsets, int64_t V, int64_t n, void* d_out_video);
+
+/* VideoHasher.finish() for a whole library at once (vpdqpy/vpdqpy.py:119; keep/drop contract of dedup.py:74-86,
+ * quality >= min_quality kept as in db/DedupeDB.py:550-553): stream compaction of the kept frame hashes in frame
+ * order. In: d_hashes n*32 B, d_quality int32[n], d_offsets int64[V+1] over the n raw frames. Out: d_out_hashes
+ * (room for n*32 B), d_out_offsets int64[V+1] over the kept frames, d_out_video int32[kept] (room for n),
+ * *out_kept. A video may end up with 0 frames (legal: dedup.py:82-86). */
+int hvd_dev_compact_kept(const void* d_hashes, const void* d_quality, int64_t n, const void* d_offsets, int64_t V,
+                         int min_quality, void* d_out_hashes, void* d_out_offsets, void* d_out_video, int64_t* out_kept);
+
+/* Every video pair a<b with >= 1 frame hit, with its vPDQ counters (semantics of vpdqpy/vpdqpy.py:49-56 for all
+ * pairs at once; replaces the tree walk of dedup.py:468-475). d_img: FP4 image of the n frame hashes; d_video:
+ * int32[n] frame -> video (frames of one video are never compared). The counters are reduced ON THE DEVICE: the
+ * all-pairs kernel records "frame f has a match in video v" in a set in HBM, which is then folded into one
+ * hvd_vmatch per video pair -- frame-level hits never leave the GPU. world > 1: this rank compares its tiles,
+ * the key sets are all-gathered over RCCL (hvd_comm_init required) and every rank returns the full result.
+ * d_out[cap] receives min(count, cap) unordered records, the uint64 at d_count the true count. max_dist in
+ * [0,127]. */
+int hvd_dev_vpdq_match_videos(const void* d_img, int64_t n, const void* d_video, int max_dist, int rank, int world,
+                              void* d_out, int64_t cap, void* d_count);
+/* Query library x target library form (VpTreeManager.search_file for a batch, db/vptree.py:865-902).
+ * d_excl_q / d_excl_t (both or neither): int32 per frame, frames with equal values are not compared. */
+int hvd_dev_vpdq_match_videos_cross(const void* d_img_q, int64_t nq, const void* d_video_q, const void* d_excl_q,
+                                    const void* d_img_t, int64_t nt, const void* d_video_t, const void* d_excl_t,
+                                    int max_dist, int rank, int world, void* d_out, int64_t cap, void* d_count);
+
+/* Workload generator (tests / bench.py, BASELINE config 5): writes n_videos * frames_per_video synthetic 64x64 gray
+ * frames for videos [v0, v0 + n_videos) to d_frames. Every frame is a pure function of (seed, video, frame index):
+ * smooth random field + noise, ~5 % exact constants; d_copy_of (int32 per video of the WHOLE library, indexed by
+ * absolute video number, or NULL): videos with copy_of[v] = s >= 0 are video s with +-2 noise per pixel. */
+int hvd_dev_synth_video_frames(void* d_frames, int64_t v0, int64_t n_videos, int frames_per_video, uint64_t seed,
+                               const void* d_copy_of);
 
 /* Host-only: the tile geometry hvd_dev_allpairs_hamming256 uses for (n, variant): a
  * tile is rows [rb*rows_per_block, +rows_per_block) x columns [cb*col_chunk, +col_chunk). */
