@@ -7,12 +7,20 @@
 
 A "step" is one brute-force all-pairs pass (256-bit Hamming, tolerance 31) over a synthetic
 hash DB resident in HBM, including the candidate-pair exchange: BASELINE.json configs[2]
-(1M hashes, ~5e11 comparisons) at N=1. For N>1 the DB grows so that the comparisons per GPU
-stay fixed (weak scaling: n = 1M*sqrt(N)); the DB is replicated, tiles of the pair matrix
-are dealt round-robin to the ranks, the only collective is the RCCL all-gather of each
-rank's candidate pairs. The frame-hashing half of the metric (configs[1]: 10k pre-decoded
-64x64 frames) is measured in the same run and reported under "frames_hashed".
+(1M hashes, ~5e11 comparisons) at N=1.
+  --mode weak   (default) the DB grows so that the comparisons per GPU stay fixed (n = 1M*sqrt(N));
+  --mode strong BASELINE configs[2] itself at every N (total work fixed);
+  --mode cfg4   BASELINE configs[3]: 10M hashes.
+The DB is replicated, tiles of the pair matrix are dealt round-robin to the ranks, the only
+collective is the RCCL all-gather of each rank's candidate pairs. Measured in the same run and
+reported in the same JSON line: the frame-hashing half of the metric (configs[1]: 10k pre-decoded
+64x64 frames), one pass of configs[3] (10M hashes) and the chained end-to-end configs[4]
+(50k videos x 64 frames: hash -> quality filter -> video search, everything resident in HBM);
+at N=1 also the 512x512 RGB24 front-end, a CLUSTERED hash DB (the regime of real frame hashes),
+a sustained run and the CPU baseline.
 
+No PyTorch: the ranks meet over hvd_amd.rendezvous (TCP on loopback; the launcher only provides
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT), the data exchange is RCCL inside the C-ABI.
 Rank 0 prints ONE JSON line. The CPU baseline (the oracle, a port -- the reference's real
 arithmetic is the absent hvdaccelerators wheel) is timed on rank 0 at N=1 only.
 """
@@ -33,6 +41,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP4_PEAK_TFLOPS = 10000.0     # dense FP4 MFMA peak (MI355X_MICROARCH.md; measured ceiling 9099)
 BYTES_PER_COMPARISON = 64      # two 32-byte operands, no reuse credited
 BYTES_PER_FRAME_64 = 4096 + 32 + 4
+BYTES_PER_FRAME_RGB512 = 786432 + 32 + 4
 
 
 def host_threads() -> int:
@@ -61,18 +70,38 @@ def host_threads() -> int:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--hashes", type=int, default=1_000_000, help="DB size at N=1")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=("weak", "strong", "cfg4"), default="weak")
+    ap.add_argument("--hashes", type=int, default=1_000_000, help="DB size at N=1 (weak/strong modes)")
     ap.add_argument("--frames", type=int, default=10_000)
     ap.add_argument("--variant", type=int, default=-1, help="all-pairs kernel variant (-1: product default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--sustain-seconds", type=float, default=12.0, help="length of the sustained leg at N=1 (0: skip)")
+    ap.add_argument("--no-extras", action="store_true", help="headline + frames_hashed only")
+    ap.add_argument("--cfg5-videos", type=int, default=50_000)
     return ap.parse_args()
 
 
+def mean_sd(xs):
+    xs = np.asarray(xs, dtype=np.float64)
+    return float(xs.mean()), float(xs.std(ddof=1)) if xs.size > 1 else 0.0
+
+
+def sig(x, digits=4):
+    return float(f"{x:.{digits}g}")
+
+
+def load_traffic(key):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
 def main():
-    # Native libraries (gloo, RCCL) print banners on fd 1; the contract is ONE JSON line on stdout.
+    # Native libraries (RCCL) print banners on fd 1; the contract is ONE JSON line on stdout.
     # Keep the real stdout aside and point fd 1 at stderr for everything else.
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
@@ -89,7 +118,8 @@ def main():
     import hvd_amd
     from hvd_amd import _lib as L
     from hvd_amd import multigpu as M
-    from hvd_amd import search, synth
+    from hvd_amd import pipeline, search, synth
+    from hvd_amd.rendezvous import Rendezvous
 
     ndev = L.device_count()
     if ndev < 1:
@@ -99,172 +129,210 @@ def main():
     dev = int(os.environ.get("HVD_FORCE_DEVICE", local_rank if local_rank < ndev else local_rank % ndev))
     lib = L.init(dev)
 
-    dist = None
-    exchange = None
+    rdzv = Rendezvous(rank, world)
+    exchange, host_ex = None, None
     exchange_kind = "none"
     hard_exit = False  # a bootstrap thread stuck inside RCCL cannot be joined: leave with os._exit
     if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        boot = M.TorchDistExchange()
-        uid = boot.broadcast_bytes(M.RcclExchange.create_unique_id() if rank == 0 else None, 128, src=0)
-        # ncclCommInitRank is collective; bound it so that a hung bootstrap degrades to the gloo exchange
-        # (reported in the JSON) instead of producing no measurement at all.
-        import threading
-
-        box = {}
-
-        def _init():
-            try:
-                box["ex"] = M.RcclExchange(rank, world, uid)
-            except Exception as exc:
-                box["err"] = exc
-
-        th = threading.Thread(target=_init, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("HVD_RCCL_INIT_TIMEOUT", "120")))
-        ok = 1 if ("ex" in box and not th.is_alive()) else 0
-        import torch
-
-        agree = torch.tensor([ok], dtype=torch.int64)
-        dist.all_reduce(agree, op=dist.ReduceOp.MIN)  # all ranks use RCCL, or none does
-        if int(agree.item()) == 1:
-            exchange = box["ex"]
+        # ncclCommInitRank is collective and bounded, so that a hung bootstrap degrades to exchanging the candidates
+        # over the control channel (reported in the JSON) instead of producing no measurement at all.
+        exchange, why, hard_exit = M.connect_rccl(rdzv, float(os.environ.get("HVD_RCCL_INIT_TIMEOUT", "120")))
+        if exchange is not None:
             exchange_kind = "rccl"
         else:
-            why = "timed out" if th.is_alive() else repr(box.get("err", "failed on another rank"))
-            print(f"[bench] rank {rank}: RCCL init {why}; exchanging candidates over gloo", file=sys.stderr)
-            exchange = None
-            exchange_kind = "gloo-fallback"
-            hard_exit = th.is_alive()
+            print(f"[bench] rank {rank}: RCCL init {why}; exchanging candidates over TCP", file=sys.stderr)
+            host_ex = M.HostExchange(rdzv)
+            exchange_kind = "tcp-fallback"
 
     def barrier():
-        # the kernels run on the library's own HIP stream, which hvd_dev_sync() drains; torch's device-wide
-        # synchronize is added when torch is loaded anyway (N > 1) so that nothing of any stream is in flight
-        L.check(lib.hvd_dev_sync())
-        if dist is not None:
-            import torch
-
-            if torch.cuda.is_available():
-                torch.cuda.synchronize(dev)  # this rank's GPU only
-            dist.barrier()
+        # the kernels run on the library's own HIP stream; hipDeviceSynchronize (every stream of this rank's GPU,
+        # RCCL's included) is the counterpart of torch.cuda.synchronize()
+        L.check(lib.hvd_device_synchronize())
+        rdzv.barrier()
 
     variant = search.DEFAULT_VARIANT if args.variant < 0 else args.variant
 
-    # ---------------- workload: replicated synthetic hash DB ---------------------------
-    n = int(round(args.hashes * math.sqrt(world) / 1024.0)) * 1024 if world > 1 else args.hashes
-    db, planted = synth.hash_db(n, seed=3)
-    d_db = L.DeviceBuffer.from_array(db)
-    img_bytes = C.c_size_t(0)
-    L.check(lib.hvd_fp4_image_bytes(n, C.byref(img_bytes)))
-    d_img = L.DeviceBuffer(img_bytes.value)
-    cap = 1 << 20
-    d_pairs = L.DeviceBuffer(16 * cap)
-    d_cnt = L.DeviceBuffer(8)
-    total_cmp = n * (n - 1) // 2
-
-    kernel_ms = []
-
-    def step(v=variant, timed=True):
-        d_cnt.zero()
-        if v >= 8:  # the FP4 image is rebuilt inside every step: it is part of the pass, not a cached index
-            L.check(lib.hvd_dev_expand_fp4(d_db.ptr, n, d_img.ptr))
-        L.check(lib.hvd_timer_start())
-        M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n, None, 31, rank, world, d_pairs.ptr, cap, d_cnt.ptr, v)
-        ms = C.c_float(0)
-        L.check(lib.hvd_timer_stop(C.byref(ms)))  # hipEvents on the library stream; also syncs
-        if timed:
-            kernel_ms.append(ms.value)
-        cnt = int(d_cnt.to_array(np.uint64, 1)[0])
-        if cnt > cap:
-            raise RuntimeError("pair buffer overflow in bench")
-        if world == 1:
-            return d_pairs.to_array(L.PAIR_DTYPE, cnt)
-        if exchange is not None:
-            return exchange.allgather_pairs_dev(d_pairs.ptr, cnt)
-        return boot.allgather_pairs(d_pairs.to_array(L.PAIR_DTYPE, cnt))
-
-    for _ in range(args.warmup):
-        step(timed=False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        recs = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        km = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64)
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kernel_avg_ms = float(km.item())
+    # ---------------- headline workload: replicated synthetic hash DB ---------------------------
+    if args.mode == "cfg4":
+        n, seed, scaling = 10_000_000, 4, "strong"
+        wl = "BASELINE configs[3]: 10M hashes"
+    elif args.mode == "strong" or world == 1:
+        n, seed, scaling = args.hashes, 3, ("weak" if world == 1 else "strong")
+        wl = "BASELINE configs[2]" if n == 1_000_000 else f"configs[2] shape at n={n}"
     else:
-        kernel_avg_ms = float(np.mean(kernel_ms))
+        n, seed, scaling = int(round(args.hashes * math.sqrt(world) / 1024.0)) * 1024, 3, "weak"
+        wl = f"configs[2] scaled weakly: n = {args.hashes}*sqrt({world})"
 
-    # parity gate that runs with every measurement: every planted pair within tolerance is
-    # reported with its exact distance, and every reported pair verifies on the host
-    merged = M.merge_pairs([recs])
-    dist_host = np.unpackbits(db[merged["i"]] ^ db[merged["j"]], axis=1).sum(1)
-    assert np.array_equal(dist_host, merged["dist"]) and (merged["dist"] <= 31).all()
-    d_pl = np.unpackbits(db[planted[:, 0]] ^ db[planted[:, 1]], axis=1).sum(1)
-    want = {(int(min(s, d)), int(max(s, d))) for (s, d, _), dd in zip(planted, d_pl) if dd <= 31}
-    assert want <= set(zip(merged["i"].tolist(), merged["j"].tolist())), "planted duplicate pair missed"
+    def allpairs_workload(n_, seed_, steps, warmup, v=variant, db_=None, planted_=None, cap=1 << 20, verify=True):
+        """K timed steps (FP4 image + all-pairs pass over this rank's tiles + pair read-back + exchange)."""
+        if db_ is None:
+            db_, planted_ = synth.hash_db(n_, seed=seed_)
+        d_db = L.DeviceBuffer.from_array(db_)
+        img_bytes = C.c_size_t(0)
+        L.check(lib.hvd_fp4_image_bytes(n_, C.byref(img_bytes)))
+        d_img = L.DeviceBuffer(img_bytes.value)
+        d_pairs = L.DeviceBuffer(16 * cap)
+        d_cnt = L.DeviceBuffer(8)
+        kms, my_pairs = [], [0]
 
+        def step(timed=True):
+            d_cnt.zero()
+            if v >= 8:  # the FP4 image is rebuilt inside every step: it is part of the pass, not a cached index
+                L.check(lib.hvd_dev_expand_fp4(d_db.ptr, n_, d_img.ptr))
+            L.check(lib.hvd_timer_start())
+            M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n_, None, 31, rank, world, d_pairs.ptr, cap, d_cnt.ptr, v)
+            ms = C.c_float(0)
+            L.check(lib.hvd_timer_stop(C.byref(ms)))  # hipEvents on the library stream; also syncs
+            if timed:
+                kms.append(ms.value)
+            cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+            if cnt > cap:
+                raise RuntimeError("pair buffer overflow in bench")
+            my_pairs[0] = cnt
+            if world == 1:
+                return d_pairs.to_array(L.PAIR_DTYPE, cnt)
+            if exchange is not None:
+                return exchange.allgather_pairs_dev(d_pairs.ptr, cnt)
+            return host_ex.allgather_pairs(d_pairs.to_array(L.PAIR_DTYPE, cnt))
+
+        for _ in range(warmup):
+            step(timed=False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            recs = step()
+        barrier()
+        elapsed = rdzv.allreduce_max([time.perf_counter() - t0])[0]
+        merged = M.merge_pairs([recs])
+        if verify:
+            # parity gate that runs with every measurement: every reported pair verifies on the host with its exact
+            # distance, and every planted pair within tolerance is reported
+            dist_host = np.unpackbits(db_[merged["i"]] ^ db_[merged["j"]], axis=1).sum(1)
+            assert np.array_equal(dist_host, merged["dist"]) and (merged["dist"] <= 31).all()
+            if planted_ is not None and len(planted_):
+                d_pl = np.unpackbits(db_[planted_[:, 0]] ^ db_[planted_[:, 1]], axis=1).sum(1)
+                want = {(int(min(s, d)), int(max(s, d))) for (s, d, _), dd in zip(planted_, d_pl) if dd <= 31}
+                assert want <= set(zip(merged["i"].tolist(), merged["j"].tolist())), "planted duplicate pair missed"
+        per_rank = rdzv.allgather(json.dumps({"kernel_ms": round(float(np.mean(kms)), 3), "pairs": my_pairs[0]}).encode())
+        res = {"elapsed": elapsed, "kernel_ms": kms, "merged": merged, "per_rank": [json.loads(p) for p in per_rank],
+               "bufs": (d_db, d_img, d_pairs, d_cnt), "db": db_}
+        return res
+
+    total_cmp = n * (n - 1) // 2
+    head = allpairs_workload(n, seed, args.steps, args.warmup)
+    d_db, d_img, d_pairs, d_cnt = head["bufs"]
+    db = head["db"]
+    elapsed, merged = head["elapsed"], head["merged"]
+    kernel_avg_ms = max(p["kernel_ms"] for p in head["per_rank"])  # the slowest rank's mean launch duration
+    k_mean, k_sd = mean_sd(head["kernel_ms"])
     ms_per_step = elapsed / args.steps * 1e3
     value = total_cmp / (elapsed / args.steps)
 
     # ---------------- frames hashed / s (BASELINE configs[1]), every rank hashes its own batch ----
-    fr = synth.frames_gray(args.frames, seed=2)
-    d_f = L.DeviceBuffer.from_array(fr)
-    d_h = L.DeviceBuffer(32 * args.frames)
-    d_q = L.DeviceBuffer(4 * args.frames)
-    reps = 20
-    L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, args.frames, 64, 64, 1, None, d_h.ptr, d_q.ptr))
-    barrier()
-    t0 = time.perf_counter()
-    L.check(lib.hvd_timer_start())
-    for _ in range(reps):
-        L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, args.frames, 64, 64, 1, None, d_h.ptr, d_q.ptr))
-    ms = C.c_float(0)
-    L.check(lib.hvd_timer_stop(C.byref(ms)))
-    barrier()
-    k1_wall = time.perf_counter() - t0
-    k1_ms = ms.value / reps
-    if dist is not None:
-        import torch
+    def time_k1(nf, reps):
+        fr_ = synth.frames_gray(min(nf, 10_000), seed=2)
+        d_f = L.DeviceBuffer(nf * 4096)
+        for r0 in range(0, nf, fr_.shape[0]):  # larger batches replicate the 10k distinct frames on the device
+            m = min(fr_.shape[0], nf - r0)
+            L.check(lib.hvd_memcpy_h2d(C.c_void_p(d_f.ptr + r0 * 4096), fr_.ctypes.data, m * 4096))
+        d_h, d_q = L.DeviceBuffer(32 * nf), L.DeviceBuffer(4 * nf)
+        L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, nf, 64, 64, 1, None, d_h.ptr, d_q.ptr))
+        barrier()
+        ks = []
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            L.check(lib.hvd_timer_start())
+            L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, nf, 64, 64, 1, None, d_h.ptr, d_q.ptr))
+            ms = C.c_float(0)
+            L.check(lib.hvd_timer_stop(C.byref(ms)))
+            ks.append(ms.value)
+        barrier()
+        wall = time.perf_counter() - t0
+        d_f.free()
+        return fr_, d_h, d_q, ks, wall
 
-        tw = torch.tensor([k1_wall, k1_ms], dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        k1_wall, k1_ms = float(tw[0].item()), float(tw[1].item())
+    fr, d_h, d_q, k1_list, k1_wall = time_k1(args.frames, 50)
+    k1_ms, k1_sd = mean_sd(k1_list)
+    k1_ms, k1_wall = rdzv.allreduce_max([k1_ms, k1_wall])
+
+    # ---------------- BASELINE configs[3] (10M hashes) and configs[4] (end to end), at every N --------------
+    cfg4 = cfg5 = None
+    if not args.no_extras:
+        if args.mode != "cfg4":
+            for b in (d_db, d_img, d_pairs, d_cnt):
+                b.free()
+            n4 = 10_000_000
+            r4 = allpairs_workload(n4, 4, steps=1, warmup=0)
+            for b in r4["bufs"]:
+                b.free()
+            cfg4 = {"workload": "BASELINE configs[3]: one all-pairs pass over 10M synthetic hashes (4.9999995e13 comparisons), "
+                                f"sharded tile-cyclically over {world} GPU(s), candidates all-gathered ({exchange_kind})",
+                    "value": sig(n4 * (n4 - 1) / 2 / r4["elapsed"], 5), "unit": "comparisons/s", "n_gpus": world,
+                    "seconds": round(r4["elapsed"], 4), "pairs_found": int(len(r4["merged"])),
+                    "per_rank": r4["per_rank"],
+                    "gate": "every planted pair within tolerance reported; every reported pair re-verified on the host"}
+            del r4
+    if not args.no_extras and (world == 1 or exchange is not None):  # the hash-shard exchange needs RCCL
+        # configs[4]: 50k videos x 64 distinct synthetic 64x64 frames, generated in HBM (13.1 GB over all ranks)
+        V, F = args.cfg5_videos, 64
+        rng = np.random.default_rng(5)
+        copy_of = np.full(V, -1, dtype=np.int32)
+        m = int(round(V * 0.02))
+        dst = rng.choice(np.arange(1, V), size=m, replace=False)
+        is_dst = np.zeros(V, dtype=bool)
+        is_dst[dst] = True
+        copy_of[dst] = rng.choice(np.flatnonzero(~is_dst), size=m)
+        d_copy = L.DeviceBuffer.from_array(copy_of)
+        v_lo, v_hi = pipeline.video_range_of_rank(V, rank, world)
+        d_frames = L.DeviceBuffer(max(1, (v_hi - v_lo) * F * 4096))
+        L.check(lib.hvd_dev_synth_video_frames(d_frames.ptr, v_lo, v_hi - v_lo, F, 5, d_copy.ptr))
+        raw_off = np.arange(V + 1, dtype=np.int64) * F
+        pipeline.dedupe_frames_on_device(d_frames.ptr, raw_off, 64, 64, 1, 50.0, None, rank, world, exchange)  # warm-up
+        times = []
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            pairs5, recs5, lib5 = pipeline.dedupe_frames_on_device(d_frames.ptr, raw_off, 64, 64, 1, 50.0, None, rank,
+                                                                   world, exchange, keep_library=True)
+            barrier()
+            times.append(rdzv.allreduce_max([time.perf_counter() - t0])[0])
+            kept5, lens5 = lib5.n_frames, lib5.lengths()
+            lib5.free()
+        d_frames.free()
+        d_copy.free()
+        planted5 = {(int(min(s, d)), int(max(s, d))) for d, s in enumerate(copy_of) if s >= 0}
+        found5 = {tuple(p) for p in pairs5.tolist()}
+        chk = rdzv.allgather(np.uint64(np.bitwise_xor.reduce(
+            recs5.view(np.uint32).astype(np.uint64) * np.arange(1, recs5.size * 4 + 1, dtype=np.uint64)) if recs5.size else 0
+        ).tobytes())
+        assert len(set(chk)) == 1, "ranks disagree on the config-5 records"
+        t5, t5_sd = mean_sd(times)
+        fcmp5 = float((lens5.sum() ** 2 - (lens5 ** 2).sum()) / 2)  # frame comparisons between different videos
+        cfg5 = {"workload": f"BASELINE configs[4]: {V} synthetic videos x {F} distinct 64x64 frames generated in HBM -> PDQ hash -> "
+                            "quality filter + CSR on the GPU -> FP4 image -> all video pairs with the vPDQ counters reduced on "
+                            f"the GPU -> pair predicate (threshold 50); {world} GPU(s): frames hashed in disjoint video ranges, "
+                            f"hash shards all-gathered, search tile-cyclic, key sets all-gathered ({exchange_kind})",
+                "seconds": round(t5, 4), "seconds_sd": round(t5_sd, 4), "n_gpus": world,
+                "frames": V * F, "frames_kept": int(kept5), "videos_per_s": sig(V / t5), "frames_per_s_end_to_end": sig(V * F / t5),
+                "frame_comparisons": fcmp5, "frame_comparisons_per_s_end_to_end": sig(fcmp5 / t5),
+                "video_records": int(len(recs5)), "duplicate_pairs": int(len(pairs5)),
+                "planted_copies": len(planted5), "planted_recall": round(len(planted5 & found5) / max(1, len(planted5)), 4),
+                "gate": "identical record checksum on every rank; tests/test_gpu_round2.py checks the same pipeline against "
+                        "the oracle (hashes of 10k frames, records of a 3000-video sub-library)"}
 
     if rank != 0:
         if exchange is not None:
             exchange.close()
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        rdzv.barrier()
+        rdzv.close()
         if hard_exit:
             os._exit(0)
         return
 
-    # kernel-level roofline (rank 0's share of the comparisons per launch)
+    # kernel-level roofline (one rank's share of the comparisons per launch)
     cmp_per_launch = total_cmp / world
     achieved = cmp_per_launch * BYTES_PER_COMPARISON / (kernel_avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = f"allpairs_n{n}_v{variant}_w{world}"
-            traffic = tj.get(key)
-        except Exception:
-            traffic = None
+    traffic = load_traffic(f"allpairs_n{n}_v{variant}_w{world}")
     hbm_equiv = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(achieved / HBM_PEAK_GBS, 3),
                  "note": "SURVEY.md 8d accounting: 64 B per comparison with no operand reuse credited; frac > 1 "
@@ -275,7 +343,7 @@ def main():
         tfl = cmp_per_launch * flop_per_cmp / (kernel_avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": f"k_allpairs_mfma(variant={variant})", "achieved": round(tfl, 1),
                     "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / FP4_PEAK_TFLOPS, 3),
-                    "traffic": traffic, "kernel_ms": round(kernel_avg_ms, 3),
+                    "traffic": traffic, "kernel_ms": round(kernel_avg_ms, 3), "kernel_ms_sd_rank0": round(k_sd, 3),
                     "instr": "v_mfma_f32_32x32x64_f8f6f4 cbsz:4 blgp:4 on the +-1 FP4 image of the hashes",
                     "flop_per_comparison_executed": flop_per_cmp, "hbm_equivalent": hbm_equiv}
     else:
@@ -284,38 +352,108 @@ def main():
                     "note": hbm_equiv["note"] + "; binding unit: integer VALU (v_bcnt_u32_b32 issues at half rate, "
                                                 "profiles/r01_ubench_valu.txt)"}
 
-    extra = {}
-    # full-popcount variant next to the default, for transparency (same DB, same launch shape)
-    if world == 1:
-        for v, name in ((0, "popcount_full_16op"), (1, "popcount_prefilter128"), (8, "mfma_fp4_full"),
-                        (9, "mfma_fp4_prefilter128")):
-            ks = []
-            for r in range(3):
-                d_cnt.zero()
-                L.check(lib.hvd_timer_start())
-                M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n, None, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, v)
-                ms = C.c_float(0)
-                L.check(lib.hvd_timer_stop(C.byref(ms)))
-                if r:
-                    ks.append(ms.value)
-            extra[name] = {"kernel_ms": round(float(np.mean(ks)), 3),
-                           "comparisons_per_s": float(f"{total_cmp / (np.mean(ks) * 1e-3):.4g}")}
-
     fps = world * args.frames / (k1_ms * 1e-3)
     frames_out = {
         "workload": f"{args.frames} pre-decoded synthetic 64x64 gray frames per GPU -> PDQ hash + quality "
                     "(BASELINE configs[1]; frames are independent, ranks hash disjoint batches, no collective)",
-        "value": float(f"{fps:.4g}"), "unit": "frames/s", "kernel_ms": round(k1_ms, 4), "dtype": "f32",
-        "n_gpus": world, "wall_value": float(f"{world * args.frames * reps / k1_wall:.4g}"),
+        "value": sig(fps), "unit": "frames/s", "kernel_ms": round(k1_ms, 4), "kernel_ms_sd": round(k1_sd, 4), "dtype": "f32",
+        "n_gpus": world, "wall_value": sig(world * args.frames * 50 / k1_wall),
         "roofline": {"bound": "hbm", "kernel": "k_pdq_hash64", "achieved": round(fps / world * BYTES_PER_FRAME_64 / 1e9, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(fps / world * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(fps / world * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": load_traffic(f"pdq_hash64_n{args.frames}"),
                      "note": "fp32-VALU-bound at 64x64 (bit-exact non-FMA DCT: 2 VALU ops per MAC; PMC: SIMDs "
                              "issue-saturated, profiles/r01_pmc_k1.txt), not HBM-bound"},
     }
+
+    out = {
+        "metric": "hash-pair comparisons/sec", "value": sig(value, 5), "unit": "comparisons/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "fp4(e2m1, +-1 image of the hash bits) x fp4 -> f32, exact" if variant >= 8 else "u32", "data": "synthetic",
+        "config": {"workload": f"all-pairs 256-bit Hamming (tolerance 31) over {n} synthetic hashes with planted "
+                               f"near-duplicates, {total_cmp:.6g} comparisons per step ({wl})",
+                   "n_hashes": n, "max_dist": 31, "kernel_variant": variant, "mode": args.mode,
+                   "parallelism": f"tile-cyclic x{world}, DB replicated, exchange={exchange_kind}",
+                   "exchange": exchange_kind, "rccl_ranks": world if exchange_kind == "rccl" else 0,
+                   "pairs_found": int(len(merged))},
+        "roofline": roofline,
+        "per_rank": head["per_rank"],
+    }
+    if cfg4:
+        out["config4"] = cfg4
+    if cfg5:
+        out["config5"] = cfg5
+
     cpu = None
-    video_match = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
+        extra = {}
+        # chip-filling batch of the 64x64 hash kernel (10k frames occupy a fraction of the 256 CUs' wave slots)
+        _, dh2, dq2, kl, _ = time_k1(400_000, 10)
+        dh2.free()
+        dq2.free()
+        m400, s400 = mean_sd(kl)
+        frames_out["batch_400k"] = {"value": sig(400_000 / (m400 * 1e-3)), "unit": "frames/s", "kernel_ms": round(m400, 3),
+                                    "kernel_ms_sd": round(s400, 3),
+                                    "hbm_frac": round(400_000 / (m400 * 1e-3) * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4)}
+
+        # the headline DB again for the side-by-side legs
+        d_db = L.DeviceBuffer.from_array(db)
+        img_bytes = C.c_size_t(0)
+        L.check(lib.hvd_fp4_image_bytes(n, C.byref(img_bytes)))
+        d_img = L.DeviceBuffer(img_bytes.value)
+        cap = 1 << 23
+        d_pairs = L.DeviceBuffer(16 * cap)
+        d_cnt = L.DeviceBuffer(8)
+        L.check(lib.hvd_dev_expand_fp4(d_db.ptr, n, d_img.ptr))
+
+        def time_variant(v, reps=5, d_db_=None, d_img_=None):
+            ks = []
+            for r in range(reps + 1):
+                d_cnt.zero()
+                L.check(lib.hvd_timer_start())
+                M.launch_allpairs(lib, (d_db_ or d_db).ptr, (d_img_ or d_img).ptr, n, None, 31, 0, 1, d_pairs.ptr, cap,
+                                  d_cnt.ptr, v)
+                ms = C.c_float(0)
+                L.check(lib.hvd_timer_stop(C.byref(ms)))
+                if r:
+                    ks.append(ms.value)
+            return mean_sd(ks) + (int(d_cnt.to_array(np.uint64, 1)[0]),)
+
+        # every exact form next to the default, for transparency (same DB, same launch shape)
+        for v, name in ((0, "popcount_full_16op"), (1, "popcount_prefilter128"), (8, "mfma_fp4_full"),
+                        (9, "mfma_fp4_prefilter128")):
+            mu, sd, _ = time_variant(v, reps=3)
+            extra[name] = {"kernel_ms": round(mu, 3), "kernel_ms_sd": round(sd, 3), "comparisons_per_s": sig(total_cmp / (mu * 1e-3))}
+        out["kernel_variants"] = extra
+
+        # CLUSTERED hash DBs: the regime of real frame hashes (static scenes, re-encodes), where many panels contain a
+        # hit and take the kernel's slow path; the uniform DB above never does.
+        clustered = {}
+        for name, (ncl, csz) in (("1e4_clusters_of_10", (10_000, 10)), ("1e3_clusters_of_100", (1_000, 100))):
+            dbc, members = synth.hash_db_clustered(n, ncl, csz, seed=8)
+            d_dbc = L.DeviceBuffer.from_array(dbc)
+            d_imgc = L.DeviceBuffer(img_bytes.value)
+            L.check(lib.hvd_dev_expand_fp4(d_dbc.ptr, n, d_imgc.ptr))
+            mu, sd, cnt = time_variant(variant, reps=5, d_db_=d_dbc, d_img_=d_imgc)
+            want_pairs = ncl * csz * (csz - 1) // 2
+            assert cnt == want_pairs, (cnt, want_pairs)  # every in-cluster pair, nothing else
+            got = d_pairs.to_array(L.PAIR_DTYPE, cnt)[:: max(1, cnt // 20000)]
+            dd = np.unpackbits(dbc[got["i"]] ^ dbc[got["j"]], axis=1).sum(1)
+            assert np.array_equal(dd, got["dist"]) and (got["i"] < got["j"]).all()
+            p_pair = (csz - 1) / n
+            clustered[name] = {"kernel_ms": round(mu, 3), "kernel_ms_sd": round(sd, 3),
+                               "comparisons_per_s": sig(total_cmp / (mu * 1e-3)), "pairs": cnt,
+                               "slow_path_share_of_panels": round(1.0 - math.exp(-8192 * p_pair), 3),
+                               "vs_uniform": round(extra["mfma_fp4_prefilter128"]["kernel_ms"] / mu, 3) if variant == 9 else None}
+            d_dbc.free()
+            d_imgc.free()
+            del dbc
+        out["clustered_db"] = {"workload": f"{n} hashes, clusters of near-identical hashes (<= 16 bits apart) scattered uniformly "
+                                           "over the DB; all in-cluster pairs must come back (count and sampled distances "
+                                           "verified); slow_path_share = expected share of (wave, 32-candidate panel) steps "
+                                           "that contain a hit", **clustered}
+
         # the reference's real frame geometry: 512x512 packed RGB24 (vpdqpy/vpdqpy.py:90-95)
         n_rgb = 6144  # two full rounds of the 3072 resident waves of k_down512w (4.8 GB of frames)
         rgb = synth.frames_rgb(16, seed=6)
@@ -327,25 +465,45 @@ def main():
         d_rs = L.DeviceBuffer(sb.value)
         d_rh = L.DeviceBuffer(32 * n_rgb)
         d_rq = L.DeviceBuffer(4 * n_rgb)
-        rgb_ms = 1e9
-        for r in range(9):  # best of 8 after a warm-up: the chip comes straight from the matrix-core workload
+        rl = []
+        for r in range(11):  # mean of 10 after a warm-up (same statistic as every other leg)
             L.check(lib.hvd_timer_start())
             L.check(lib.hvd_dev_pdq_hash_frames(d_rf.ptr, n_rgb, 512, 512, 3, d_rs.ptr, d_rh.ptr, d_rq.ptr))
             ms = C.c_float(0)
             L.check(lib.hvd_timer_stop(C.byref(ms)))
             if r:
-                rgb_ms = min(rgb_ms, ms.value)
+                rl.append(ms.value)
+        rgb_ms, rgb_sd = mean_sd(rl)
         rgb_fps = n_rgb / (rgb_ms * 1e-3)
         frames_out["rgb24_512x512"] = {
             "workload": f"{n_rgb} pre-decoded synthetic 512x512 RGB24 frames (the reference's hash_frame input): luma + "
                         "2x Jarosz + decimate (k_down512w, one wave per frame) + k_pdq_hash64",
-            "value": float(f"{rgb_fps:.4g}"), "unit": "frames/s", "ms": round(rgb_ms, 3),
-            "roofline": {"bound": "hbm", "achieved": round(rgb_fps * 786468 / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(rgb_fps * 786468 / 1e9 / HBM_PEAK_GBS, 3), "traffic": None,
-                         "note": "algorithmic bytes = 786432 in + 36 out per frame. Memory-side traffic is 1.26 MB per frame "
-                                 "(PMC, profiles/r01_pmc_down512w.txt: 192-byte runs re-fetch a shared 128-byte line, plus the "
-                                 "pass-B state scratch), against a streaming ceiling of 6.2 TB/s for this access shape "
-                                 "(profiles/r01_ubench_hbm_runs.txt) and an instruction floor of ~5e6 frames/s"}}
+            "value": sig(rgb_fps), "unit": "frames/s", "ms": round(rgb_ms, 3), "ms_sd": round(rgb_sd, 3),
+            "roofline": {"bound": "hbm", "kernel": "k_down512w", "achieved": round(rgb_fps * BYTES_PER_FRAME_RGB512 / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(rgb_fps * BYTES_PER_FRAME_RGB512 / 1e9 / HBM_PEAK_GBS, 3),
+                         "traffic": load_traffic(f"down512w_rgb_n{n_rgb}"),
+                         "note": "algorithmic bytes = 786432 in + 36 out per frame; `traffic` = PMC bytes per launch "
+                                 "(FETCH_SIZE x2 + WRITE_SIZE, profiles/)"}}
+
+        # sustained: the headline pass back to back with no host synchronisation in between (power/thermal steady state)
+        if args.sustain_seconds > 0:
+            reps = max(10, int(args.sustain_seconds / (k_mean * 1e-3)))
+            d_cnt.zero()
+            L.check(lib.hvd_timer_start())
+            for _ in range(reps):
+                if variant >= 8:
+                    L.check(lib.hvd_dev_expand_fp4(d_db.ptr, n, d_img.ptr))
+                M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n, None, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, variant)
+            ms = C.c_float(0)
+            L.check(lib.hvd_timer_stop(C.byref(ms)))
+            assert int(d_cnt.to_array(np.uint64, 1)[0]) == reps * len(merged)
+            out["sustained"] = {"what": f"{reps} passes (FP4 image + all-pairs) enqueued back to back, one synchronisation at the end",
+                                "seconds": round(ms.value / 1e3, 2), "ms_per_pass": round(ms.value / reps, 3),
+                                "comparisons_per_s": sig(total_cmp / (ms.value / reps * 1e-3))}
+        for b in (d_db, d_img, d_pairs, d_cnt):
+            b.free()
+
         if not args.no_cpu_baseline:
             from oracle import oracle as O  # cpu_baseline leg only
 
@@ -378,7 +536,7 @@ def main():
             qr = d_rq.to_array(np.int32, n_rgb)
             assert (np.array_equal(hr, np.tile(hro[:16], (n_rgb // 16, 1))) and
                     np.array_equal(qr, np.tile(qro[:16], n_rgb // 16))), "GPU rgb512 hashes differ from the oracle"
-            frames_out["rgb24_512x512"]["cpu_frames_per_s"] = float(f"{256 / dtr:.4g}")
+            frames_out["rgb24_512x512"]["cpu_frames_per_s"] = sig(256 / dtr)
             # K3: 2000 videos x 64 frame hashes, every video pair; host buffers in, records out
             vfr, voff, _ = synth.video_hashes(2000, seed=7, frames_per_video=64, copy_fraction=0.02)
             search.match_videos(vfr[:6400], voff[:101])  # warm
@@ -390,39 +548,22 @@ def main():
             dt_c = time.perf_counter() - t
             assert np.array_equal(rec_g, rec_c), "GPU video-match records differ from the oracle"
             k3_cmp = 2000 * 1999 // 2 * 4096
-            video_match = {"workload": "2000 synthetic videos x 64 frame hashes, all video pairs (hvd_vpdq_match_videos, "
-                                       "host buffers in, match records out)",
-                           "value": float(f"{k3_cmp / dt_g:.4g}"), "unit": "frame comparisons/s", "ms": round(dt_g * 1e3, 2),
-                           "records": int(len(rec_g)), "cpu_value": float(f"{k3_cmp / dt_c:.4g}"), "cpu_threads": 1,
-                           "note": "small problem: transfer + launch overheads dominate the GPU figure (config 5, 50k "
-                                   "videos, runs at the all-pairs kernel's rate: scripts/e2e_config5.py)"}
-            cpu = {"value": float(f"{cpu_cmp:.4g}"), "unit": "comparisons/s", "cores": cores, "kind": "port",
+            out["video_match"] = {"workload": "2000 synthetic videos x 64 frame hashes, all video pairs (hvd_vpdq_match_videos, "
+                                              "host buffers in, video-level records out; counters reduced on the GPU)",
+                                  "value": sig(k3_cmp / dt_g), "unit": "frame comparisons/s", "ms": round(dt_g * 1e3, 2),
+                                  "records": int(len(rec_g)), "cpu_value": sig(k3_cmp / dt_c), "cpu_threads": 1,
+                                  "note": "small problem: transfer + launch overheads dominate the GPU figure; config5 above is "
+                                          "the same path at full size"}
+            cpu = {"value": sig(cpu_cmp), "unit": "comparisons/s", "cores": cores, "kind": "port",
                    "sample": f"oracle (C, popcnt, pthreads) all-pairs over the first {ns} of the {n} hashes "
                              f"({ns * (ns - 1) // 2:.3g} comparisons, {dt:.1f} s)",
-                   "value_1thread": float(f"{cpu_cmp_1t:.4g}"),
+                   "value_1thread": sig(cpu_cmp_1t),
                    "speedup_over_1thread": round(cpu_cmp / cpu_cmp_1t, 1), "os_cpu_count": os.cpu_count(),
-                   "frames_per_s": float(f"{args.frames / dtf:.4g}"),
+                   "frames_per_s": sig(args.frames / dtf),
                    "frames_sample": f"oracle PDQ over the same {args.frames} frames, {cores} threads, {dtf:.2f} s",
                    "note": "the reference's real CPU path (hvdaccelerators 0.4.0) is not installable offline; this "
                            "is the oracle port"}
 
-    out = {
-        "metric": "hash-pair comparisons/sec", "value": float(f"{value:.5g}"), "unit": "comparisons/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp4(e2m1, +-1 image of the hash bits) x fp4 -> f32, exact" if variant >= 8 else "u32", "data": "synthetic",
-        "config": {"workload": f"all-pairs 256-bit Hamming (tolerance 31) over {n} synthetic hashes with planted "
-                               f"near-duplicates, {total_cmp:.6g} comparisons per step"
-                               + (" (BASELINE configs[2])" if world == 1 and n == 1_000_000 else
-                                  f" (configs[2] scaled weakly: n = 1M*sqrt({world}))"),
-                   "n_hashes": n, "max_dist": 31, "kernel_variant": variant,
-                   "parallelism": f"tile-cyclic x{world}, DB replicated, exchange={exchange_kind}",
-                   "pairs_found": int(len(merged))},
-        "roofline": roofline,
-    }
-    if extra:
-        out["kernel_variants"] = extra
-    if world == 1:
         # the reference-shaped loop -- one Python call per video pair, as db/vptree.py:29-31,737 issues them
         # (tests/benchmarks/test_benchmark_vpdqpy.py:62-73 has the same shape). 64-frame hashes, 1024 calls.
         vf, voff, _ = synth.video_hashes(33, seed=1, frames_per_video=64, copy_fraction=0.1)
@@ -439,21 +580,18 @@ def main():
             "what": "calculate_distance(a, b) = fix_vpdq_similarity(matchHashBytes(a, b, 31)) on 64-frame video hashes, "
                     "one call per pair from Python (the reference's VP-tree call pattern)",
             "us_per_call": round(per_call * 1e6, 1), "calls": ncall,
-            "frame_comparisons_per_s": float(f"{4096 / per_call:.3g}"),
+            "frame_comparisons_per_s": sig(4096 / per_call, 3),
             "note": "launch-bound by construction; the batch entry points above replace the loop, not the callee"}
-    if frames_out:
-        out["frames_hashed"] = frames_out
-    if video_match:
-        out["video_match"] = video_match
+
+    out["frames_hashed"] = frames_out
     if cpu:
         out["cpu_baseline"] = cpu
     real_stdout.write(json.dumps(out) + "\n")
     real_stdout.flush()
     if exchange is not None:
         exchange.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rdzv.barrier()
+    rdzv.close()
     if hard_exit:
         os._exit(0)
 

@@ -56,9 +56,11 @@ SIGNATURES = {
     "hvd_memcpy_d2h": (_int, [_vp, _vp, _sz]),
     "hvd_memcpy_d2d": (_int, [_vp, _vp, _sz]),
     "hvd_dev_sync": (_int, []),
+    "hvd_device_synchronize": (_int, []),
     "hvd_set_pdq_dct_mode": (_int, [_int]),
     "hvd_get_pdq_dct_mode": (_int, []),
     "hvd_debug_set": (_int, [C.c_char_p, _int]),
+    "hvd_debug_get": (_int, [C.c_char_p, C.POINTER(_int)]),
     "hvd_pdq_scratch_bytes": (_int, [_i64, _int, _int, _int, C.POINTER(_sz)]),
     "hvd_dev_pdq_hash_frames": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "hvd_dev_allpairs_hamming256": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _i64, _vp, _int]),

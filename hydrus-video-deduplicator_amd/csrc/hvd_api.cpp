@@ -228,6 +228,7 @@ int hvd_shutdown(void) {
     for (void* p : g.scr)
         if (p) (void)hipFree(p);
     if (g.m_pin) (void)hipHostFree(g.m_pin);
+    hvd::mfma_release();
     g.~Ctx();
     new (&g) Ctx();
     return HVD_OK;
@@ -277,6 +278,12 @@ int hvd_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes) {
 int hvd_dev_sync(void) {
     if (int rc = need_ready()) return rc;
     HIP_TRY(hipStreamSynchronize(g.stream));
+    return HVD_OK;
+}
+
+int hvd_device_synchronize(void) {
+    if (int rc = need_ready()) return rc;
+    HIP_TRY(hipDeviceSynchronize());
     return HVD_OK;
 }
 
@@ -345,6 +352,21 @@ int hvd_debug_set(const char* key, int value) {
     }
     if (strcmp(key, "pdq_fused_down512") == 0) {
         hvd::g_pdq_fused_down512 = value != 0;
+        return HVD_OK;
+    }
+    return fail(HVD_ERR_ARG, "unknown debug key %s", key);
+}
+
+int hvd_debug_get(const char* key, int* out_value) {
+    if (int rc = need_ready()) return rc;
+    if (!key || !out_value) return fail(HVD_ERR_ARG, "NULL argument");
+    if (strcmp(key, "mfma_auto_form") == 0 || strcmp(key, "mfma_probe_survivors") == 0) {
+        uint32_t* sel = nullptr;
+        HIP_TRY(hvd::mfma_select_buffer(&sel));
+        uint32_t v[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(v, sel, 8, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        *out_value = (int)v[key[5] == 'a' ? 0 : 1];
         return HVD_OK;
     }
     return fail(HVD_ERR_ARG, "unknown debug key %s", key);

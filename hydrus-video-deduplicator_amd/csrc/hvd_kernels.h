@@ -36,6 +36,8 @@ hipError_t launch_allpairs_mfma(const AllPairsArgs& a, const void* d_img, hipStr
 // for queries and d_group_t for targets; pass both or neither).
 hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
                              const int32_t* d_group_t, hipStream_t s);
+hipError_t mfma_select_buffer(uint32_t** out);  // [0] = form the auto variant ran last, [1] = probe survivors
+void mfma_release();
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 
 // Video-level reduction and quality compaction (k_vmatch.hip).

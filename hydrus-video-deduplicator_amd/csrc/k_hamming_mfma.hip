@@ -99,48 +99,62 @@ constexpr int kSuper = 128;  // candidates per LDS super-panel (256: -4 % with t
 
 __device__ __forceinline__ v4i as_v4i(const uint4& v) { return v4i{(int)v.x, (int)v.y, (int)v.z, (int)v.w}; }
 
-template <bool PREFILTER>
-__device__ __forceinline__ v16f tile_dot(const v4i (&a)[4], const v4i (&b)[4]) {
-    const v16f z = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    v16f acc = mfma_fp4(a[0], b[0], z);
-    acc = mfma_fp4(a[1], b[1], acc);
-    if (!PREFILTER) {
-        acc = mfma_fp4(a[2], b[2], acc);
-        acc = mfma_fp4(a[3], b[3], acc);
-    }
+// k-steps [S0, S1) of a 32x32 tile: 64 hash bits per step.
+template <int S0, int S1>
+__device__ __forceinline__ v16f tile_dot(const v4i* a, const v4i* b, v16f acc) {
+#pragma unroll
+    for (int s = S0; s < S1; ++s) acc = mfma_fp4(a[s], b[s], acc);
     return acc;
 }
 
-// Rare path: some pair of this 32-candidate panel may be within tolerance. Recompute every
-// query tile of the wave over all 256 bits (A fragments are re-read from memory so that the
-// loop stays rolled and the fast path's registers stay untouched) and report the hits.
-// rect = false: one set, pairs i<j, group[i] != group[j]. rect = true: query set x target set
-// (row index into the query image, column index into the target image), every (i<nq, j<n) pair.
+// Everything the hit handler needs that is uniform over the launch (one kernel argument).
+struct HitCtx {
+    const int32_t* group;    // rows (nullable)
+    const int32_t* group_t;  // columns of the rectangular form
+    hvd_pair* out;
+    unsigned long long cap;
+    unsigned long long* count;
+    hvd::VideoSink vs;
+    uint32_t n, nq;
+    float thr_full, inv_scale2;
+    uint32_t rect;
+};
+
+// Hits of one 32x32 tile whose accumulators hold the full 256-bit dot products: acc[r] belongs to
+// row = row0 + (r&3) + 8*(r>>2) + 4*(lane>>5), column j (C/D layout of the 32x32 MFMA).
+// rect = 0: one set, pairs i<j, group[i] != group[j]. rect = 1: query set x target set (row index into the
+// query image, column index into the target image), every (i<nq, j<n) pair.
 //
 // Two sinks. Frame-pair mode (vs.set == nullptr): one hvd_pair per hit. Video mode (K3): a hit (i, j) means
 // "frame i has a match in video(j)" and "frame j has a match in video(i)"; those two facts go into the
-// device set as keys, de-duplicated inside the panel before any atomic is issued: frames are stored in video
+// device set as keys, de-duplicated inside the tile before any atomic is issued: frames are stored in video
 // order, so the 32 columns of a panel and the rows a lane walks both visit videos monotonically -- a row key is
 // issued only by the first hit column of its video (ballot of the row's hits against the panel's video
-// segments), a column key only when the row video changes. A panel in which every pair matches (two copies of
-// one video) costs 2 atomics per row and column instead of 1024 appends.
-template <int TILES>
-__device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, const uint4* base, uint32_t sw,
-                                             uint32_t wrow0, uint32_t j, uint32_t n, uint32_t h, uint32_t li,
-                                             const int32_t* __restrict__ group, float thr_full,
-                                             hvd_pair* __restrict__ out, unsigned long long cap,
-                                             unsigned long long* __restrict__ count, bool rect, uint32_t nq,
-                                             const int32_t* __restrict__ group_t, float inv_scale2,
-                                             const hvd::VideoSink vs) {
-    v4i bf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) bf[s] = as_v4i(base[(2u * s + h) ^ sw]);
-    const bool video = vs.set != nullptr;
-    const int32_t gcol = (group != nullptr && j < n) ? (rect ? group_t[j] : group[j]) : 0;
+// segments), a column key only when the row video changes. A tile in which every pair matches (two copies of
+// one video) costs ~2 atomics per row and column instead of 1024 appends.
+// A pointer argument of a non-kernel function arrives in VGPRs; make it provably uniform and constant so that the
+// context is fetched with scalar loads into SGPRs (as flat loads it occupied ~30 VGPRs, which add to the fast path's
+// register footprint: the handlers' registers and the values their caller keeps live across the call must coexist).
+__device__ __forceinline__ HitCtx load_ctx(const HitCtx* ctx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long praw = (unsigned long long)ctx;
+    const unsigned long long puni = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(praw >> 32)) << 32) |
+                                    (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)praw);
+    return *(const __attribute__((address_space(4))) HitCtx*)puni;
+#else
+    return *ctx;
+#endif
+}
+
+__device__ __forceinline__ void tile_hits_body(const v16f& acc, uint32_t row0, uint32_t j, uint32_t lane, const HitCtx& c) {
+    const uint32_t li = lane & 31u, h = lane >> 5;
+    const bool video = c.vs.set != nullptr;
+    const bool rect = c.rect != 0u;
+    const int32_t gcol = (c.group != nullptr && j < c.n) ? (rect ? c.group_t[j] : c.group[j]) : 0;
     int32_t vcol = -1, last_v = -1;
     uint32_t lowmask = 0;
     if (video) {
-        vcol = j < n ? vs.vid_t[j] : -1;
+        vcol = j < c.n ? c.vs.vid_t[j] : -1;
         const int32_t vprev = __shfl_up(vcol, 1);
         const unsigned long long seg = __ballot(li == 0u || vcol != vprev);  // first column of each video in the panel
         const uint32_t segh = h ? (uint32_t)(seg >> 32) : (uint32_t)seg;
@@ -148,35 +162,60 @@ __device__ __noinline__ void panel_slow_path(const uint4* __restrict__ img, cons
         const uint32_t segstart = 31u - (uint32_t)__clz((int)upto);
         lowmask = ((1u << li) - 1u) & ~((1u << segstart) - 1u);  // lower columns of my video
     }
+    // rolled on purpose: the handler's register footprint adds to the fast path's (its caller keeps ~110 values
+    // live across the call), and 16 unrolled iterations cost 40 more VGPRs = one resident wave per SIMD
 #pragma unroll 1
-    for (int t = 0; t < TILES; ++t) {
-        const uint32_t hash = wrow0 + 32u * t + li;
-        v4i af[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) af[s] = as_v4i(img[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
-        const v16f acc = tile_dot<false>(af, bf);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-            const uint32_t i = wrow0 + 32u * t + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h;
-            bool ok = acc[r] >= thr_full && j < n && (rect ? i < nq : i < j);
-            if (ok && group != nullptr) ok = group[i] != gcol;
-            if (!video) {
-                if (ok) append_pair_m(out, cap, count, i, j, (uint32_t)(256 - (int)(acc[r] * inv_scale2)) >> 1);
-                continue;
-            }
-            const unsigned long long rowhits = __ballot(ok);
-            if (rowhits == 0ull) continue;  // wave-uniform
-            const uint32_t mine = h ? (uint32_t)(rowhits >> 32) : (uint32_t)rowhits;
-            if (ok) {
-                if ((mine & lowmask) == 0u) hvd::sink_insert(vs, hvd::vkey_make(0u, i, (uint32_t)vcol));
-                const int32_t vrow = vs.vid_q[i];
-                if (vrow != last_v) {
-                    hvd::sink_insert(vs, hvd::vkey_make(rect ? 1u : 0u, j, (uint32_t)vrow));
-                    last_v = vrow;
-                }
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t i = row0 + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h;
+        bool ok = acc[r] >= c.thr_full && j < c.n && (rect ? i < c.nq : i < j);
+        if (ok && c.group != nullptr) ok = c.group[i] != gcol;
+        if (!video) {
+            if (ok) append_pair_m(c.out, c.cap, c.count, i, j, (uint32_t)(256 - (int)(acc[r] * c.inv_scale2)) >> 1);
+            continue;
+        }
+        const unsigned long long rowhits = __ballot(ok);
+        if (rowhits == 0ull) continue;  // wave-uniform
+        const uint32_t mine = h ? (uint32_t)(rowhits >> 32) : (uint32_t)rowhits;
+        if (ok) {
+            if ((mine & lowmask) == 0u) hvd::sink_insert(c.vs, hvd::vkey_make(0u, i, (uint32_t)vcol));
+            const int32_t vrow = c.vs.vid_q[i];
+            if (vrow != last_v) {
+                hvd::sink_insert(c.vs, hvd::vkey_make(rect ? 1u : 0u, j, (uint32_t)vrow));
+                last_v = vrow;
             }
         }
+    }
+}
+
+__device__ __noinline__ void tile_hits(const v16f acc, uint32_t row0, uint32_t j, uint32_t lane,
+                                       const HitCtx* __restrict__ ctx) {
+    const HitCtx c = load_ctx(ctx);
+    tile_hits_body(acc, row0, j, lane, c);
+}
+
+// Deferred form of the same for the kernels whose query fragments hold only the first 128 bits: `flagged` has one bit
+// per query tile of the wave whose first stage found a candidate in this 32-candidate panel. Those tiles are
+// recomputed over all 256 bits, one k-step at a time straight from memory (few registers: see load_ctx), and their
+// hits reported.
+template <int TILES>
+__device__ __noinline__ void panel_survivors(uint32_t flagged, const uint4* __restrict__ imgq, const uint4* base, uint32_t sw,
+                                             uint32_t wrow0, uint32_t j, uint32_t lane, const HitCtx* __restrict__ ctx) {
+    const HitCtx c = load_ctx(ctx);
+    const uint32_t li = lane & 31u, h = lane >> 5;
+    const int thr2_bits = __float_as_int(c.thr_full);
+#pragma unroll 1
+    for (int t = 0; t < TILES; ++t) {
+        if (!((flagged >> t) & 1u)) continue;  // wave-uniform
+        const uint32_t hash = wrow0 + 32u * (uint32_t)t + li;
+        v16f acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (uint32_t s_ = 0; s_ < 4u; ++s_) {
+            const v4i af = as_v4i(imgq[(size_t)hash * 8u + img_slot(hash, 2u * s_ + h)]);
+            const v4i bf = as_v4i(base[(2u * s_ + h) ^ sw]);
+            acc = mfma_fp4(af, bf, acc);
+        }
+        if (!__any(max16_bits(acc) >= thr2_bits)) continue;
+        tile_hits_body(acc, wrow0 + 32u * (uint32_t)t, j, lane, c);
     }
 }
 
@@ -196,20 +235,33 @@ __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src,
     }
 }
 
+// The all-pairs kernel. Three numbers select the form (all exact, all bit-identical in their output):
+//   TILES  query tiles of 32 hashes per wave (4 waves per workgroup);
+//   S1     k-steps of the first stage: 4 = the whole 256-bit dot product at once; 2 = the first 128 bits, which
+//          bound the distance from below (a partial distance above the tolerance implies a full one above it), and
+//          only the rare tile that survives goes on to the other 128 bits;
+//   NBR    k-steps of the query fragments that live in registers: with S1 = 2 either 2 (the survivor's other half
+//          is fetched from memory: cheapest first stage, best when survivors are very rare -- uniform random
+//          hashes) or 4 (the second stage runs out of registers: robust when the first 128 bits of unrelated
+//          hashes often agree -- real frame hashes are far from uniform).
+// Each tile is judged on its own: reduce its 16 accumulators, one wave-uniform branch, and the survivors' second
+// stage / hit handler work on exactly that tile's accumulators -- nothing is recomputed.
 // RECT = false: img_q == img (one set, strict upper triangle). RECT = true: rows come from the
 // query image img_q (nq hashes), candidates from the target image img (n hashes), full rectangle.
-template <int TILES, bool PREFILTER, bool RECT>
+template <int TILES, int NBR, int S1, bool RECT>
 __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
-                                                          const int32_t* __restrict__ group, uint32_t max_dist,
-                                                          uint32_t col_chunk, uint32_t rank, uint32_t world,
-                                                          hvd_pair* __restrict__ out, unsigned long long cap,
-                                                          unsigned long long* __restrict__ count,
-                                                          const uint4* __restrict__ img_q, uint32_t nq,
-                                                          const int32_t* __restrict__ group_t, float scale2,
-                                                          const hvd::VideoSink vs) {
+                                                          uint32_t max_dist, uint32_t col_chunk, uint32_t rank,
+                                                          uint32_t world, const uint4* __restrict__ img_q, float scale2,
+                                                          const HitCtx* __restrict__ ctx,
+                                                          const uint32_t* __restrict__ select, uint32_t select_id) {
+    static_assert(S1 == 2 || S1 == 4, "first stage = 128 or 256 bits");
+    static_assert(NBR >= S1 && (NBR == 2 || NBR == 4), "register-resident k-steps");
     constexpr uint32_t WROWS = 32u * TILES, ROWS = 4u * WROWS;
-    constexpr int NB = PREFILTER ? 2 : 4;
     __shared__ uint4 lds0[kSuper * 8], lds1[kSuper * 8];
+
+    // data-dependent choice between two forms of this kernel (launch_allpairs_auto): both are launched, the
+    // probe's verdict lets one of them run
+    if (select != nullptr && *select != select_id) return;
 
     const uint32_t rb = blockIdx.x, cb = blockIdx.y;
     const uint32_t row0 = rb * ROWS;
@@ -225,22 +277,24 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     const uint32_t wrow0 = row0 + wave * WROWS;
 
     // A fragments: query hash (wrow0 + 32t + li), chunk 2s+h, for the whole tile.
-    v4i a[TILES][4];
+    v4i a[TILES][NBR];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
         const uint32_t hash = wrow0 + 32u * t + li;  // < n_pad by construction
 #pragma unroll
-        for (int s = 0; s < NB; ++s) a[t][s] = as_v4i(imgq[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
+        for (int s = 0; s < NBR; ++s) a[t][s] = as_v4i(imgq[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
     }
 
     // every product is +-v*v = +-scale2, so all dot products (and thresholds) scale by scale2
-    const float thr_full = scale2 * (256.0f - 2.0f * (float)max_dist);                       // > 0 (host guarantees)
-    const float thr_fast = PREFILTER ? scale2 * (128.0f - 2.0f * (float)max_dist) : thr_full;  // may be <= 0: then every
-    const int thr_bits = thr_fast > 0.0f ? __float_as_int(thr_fast) : (int)0x80000000;  // panel takes the slow path
+    const float thr_full = scale2 * (256.0f - 2.0f * (float)max_dist);                     // > 0 (host guarantees)
+    const float thr_fast = S1 == 2 ? scale2 * (128.0f - 2.0f * (float)max_dist) : thr_full;  // > 0 (host guarantees)
+    const int thr1_bits = __float_as_int(thr_fast), thr2_bits = __float_as_int(thr_full);
 
     // candidates <= row0 cannot pair with rows >= row0 (i<j): start at the super-panel holding row0+1
     const uint32_t j0 = RECT ? col0 : max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
     const uint32_t nsp = (col1 - j0) / kSuper;  // col0, col1, j0 are multiples of kSuper
+
+    const v16f zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
     // The two LDS buffers are separate objects and the super-panel loop is unrolled by two, so that every
     // ds_read names one array and every in-flight global->LDS load the other: with one two-dimensional array
@@ -253,24 +307,46 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
             const uint32_t cl = 32u * p + li;  // candidate index inside the super-panel
             const uint4* base = &panel[cl * 8u];
             const uint32_t sw = (cl >> 1) & 7u;  // jsp is a multiple of 128: same swizzle as the global index
-            v4i b[4];
+            v4i b[S1];
 #pragma unroll
-            for (int s = 0; s < NB; ++s) b[s] = as_v4i(base[(2u * s + h) ^ sw]);
+            for (int s = 0; s < S1; ++s) b[s] = as_v4i(base[(2u * s + h) ^ sw]);
 
-            // two accumulator sets: the MFMAs of tile t+1 run under the max tree of tile t
-            int mm = (int)0x80000000;
-            v16f cur = tile_dot<PREFILTER>(a[0], b);
+            // two accumulator sets: the MFMAs of tile t+1 are issued before the max tree of tile t
+            if constexpr (NBR == 2) {
+                // survivors are only noted (one bit per tile, scalar) and dealt with after the panel, when no
+                // accumulator is live any more: the handler's registers add to whatever is live across its call
+                uint32_t flagged = 0;
+                v16f cur = tile_dot<0, S1>(a[0], b, zero);
 #pragma unroll
-            for (int t = 1; t < TILES; ++t) {
-                const v16f nxt = tile_dot<PREFILTER>(a[t], b);
-                mm = max(mm, max16_bits(cur));  // runs in the shadow of tile t's MFMAs (other accumulator set)
-                cur = nxt;
+                for (int t = 1; t < TILES; ++t) {
+                    const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
+                    flagged |= __any(max16_bits(cur) >= thr1_bits) ? (1u << (t - 1)) : 0u;
+                    cur = nxt;
+                }
+                flagged |= __any(max16_bits(cur) >= thr1_bits) ? (1u << (TILES - 1)) : 0u;
+                if (__builtin_expect(flagged != 0u, 0)) panel_survivors<TILES>(flagged, imgq, base, sw, wrow0, jsp + cl, lane, ctx);
+            } else {
+                // each tile is judged on its own: a survivor's second stage runs out of registers at once, and only a
+                // tile with a real hit (all 256 bits) calls the handler
+                auto survivor = [&](const int t, v16f acc) {
+                    if (S1 == 2) {
+                        v4i b2[2];
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) b2[s] = as_v4i(base[(2u * (s + 2) + h) ^ sw]);
+                        acc = tile_dot<0, 2>(&a[t][2], b2, acc);
+                        if (!__any(max16_bits(acc) >= thr2_bits)) return;
+                    }
+                    tile_hits(acc, wrow0 + 32u * (uint32_t)t, jsp + cl, lane, ctx);
+                };
+                v16f cur = tile_dot<0, S1>(a[0], b, zero);
+#pragma unroll
+                for (int t = 1; t < TILES; ++t) {
+                    const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
+                    if (__builtin_expect(__any(max16_bits(cur) >= thr1_bits), 0)) survivor(t - 1, cur);
+                    cur = nxt;
+                }
+                if (__builtin_expect(__any(max16_bits(cur) >= thr1_bits), 0)) survivor(TILES - 1, cur);
             }
-            mm = max(mm, max16_bits(cur));
-
-            if (__builtin_expect(__any(mm >= thr_bits), 0))
-                panel_slow_path<TILES>(imgq, base, sw, wrow0, jsp + cl, n, h, li, group, thr_full, out, cap, count,
-                                       RECT, nq, group_t, 1.0f / scale2, vs);
         }
     };
 
@@ -288,6 +364,59 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
         process(lds1, jsp + kSuper);
         __syncthreads();
     }
+}
+
+// Probe for the data-dependent choice of the kernel form: over a strided sample of the two images (up to 4096 rows
+// x 4096 columns), how often do the first 128 bits of two hashes agree to within the tolerance? In the FP4 image a
+// differing bit is a differing sign nibble, so the partial distance is popcount((x ^ y) & 0x88888888) over chunks
+// 0..3. One lane per sample row, 256 sample columns per workgroup broadcast from LDS. select[1] += survivors.
+constexpr uint32_t kProbeRows = 4096, kProbeCols = 4096;
+
+__device__ __forceinline__ uint32_t sign_diff(const uint4& x, const uint4& y) {
+    return __popc((x.x ^ y.x) & 0x88888888u) + __popc((x.y ^ y.y) & 0x88888888u) + __popc((x.z ^ y.z) & 0x88888888u) +
+           __popc((x.w ^ y.w) & 0x88888888u);
+}
+
+__global__ __launch_bounds__(256) void k_prefilter_probe(const uint4* __restrict__ img_q, uint32_t nq,
+                                                         const uint4* __restrict__ img_t, uint32_t nt, uint32_t max_dist,
+                                                         uint32_t* __restrict__ select) {
+    __shared__ uint4 cols[256][4];
+    const uint32_t rows = min(nq, kProbeRows), ncols = min(nt, kProbeCols);
+    const uint32_t rstride = nq / rows, cstride = nt / ncols;
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t ri = min(r, rows - 1u) * rstride;
+    uint4 q[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) q[c] = img_q[(size_t)ri * 8u + img_slot(ri, c)];
+    // columns sit half a stride off the rows so that, in the symmetric form, a sample row never meets itself
+    const uint32_t c = blockIdx.y * 256u + threadIdx.x;
+    const uint32_t ci = min(min(c, ncols - 1u) * cstride + cstride / 2u, nt - 1u);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) cols[threadIdx.x][k] = img_t[(size_t)ci * 8u + img_slot(ci, k)];
+    __syncthreads();
+    const uint32_t m = blockIdx.y * 256u >= ncols ? 0u : min(256u, ncols - blockIdx.y * 256u);
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t d = sign_diff(q[0], cols[k][0]) + sign_diff(q[1], cols[k][1]) + sign_diff(q[2], cols[k][2]) +
+                           sign_diff(q[3], cols[k][3]);
+        cnt += d <= max_dist ? 1u : 0u;
+    }
+    if (r >= rows) cnt = 0;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63u) == 0u && cnt) atomicAdd(&select[1], cnt);
+}
+
+// The hit handler's launch-uniform arguments live in device memory (written by this one-lane kernel in stream order
+// in front of the pass), so that the rare handler call passes one pointer instead of ~30 argument registers that the
+// fast path's register allocation would have to keep clear.
+__global__ void k_set_hit_ctx(HitCtx* __restrict__ dst, const HitCtx src) { *dst = src; }
+
+// survivors among `pairs` sampled pairs -> form: the fetch form (id_rare) pays ~6 panel steps per surviving tile, the
+// register form (id_often) a flat ~5 %: switch when more than ~1 % of the (wave, panel) steps would see a survivor.
+__global__ void k_probe_decide(uint32_t* __restrict__ select, uint64_t pairs, uint32_t pairs_per_step, uint32_t id_rare,
+                               uint32_t id_often) {
+    const double rate = pairs ? (double)select[1] / (double)pairs : 0.0;
+    select[0] = rate * (double)pairs_per_step > 0.01 ? id_often : id_rare;
 }
 
 }  // namespace
@@ -328,61 +457,151 @@ static uint32_t pick_col_chunk_m(uint32_t n_pad, uint32_t rows_per_wg) {
     return (uint32_t)chunk;
 }
 
-static int mfma_tiles(int variant) {
+struct MfmaForm {
+    int tiles, nbr, s1;
+};
+// variants: 8 = 256 bits at once; 9 = 128-bit first stage, survivors fetch their other half (default for uniform
+// data); 10 / 11 = the same with 4 tiles per wave; 12 = 128-bit first stage, second stage out of registers (4 tiles);
+// 13 = 9 or 12, chosen per launch by the probe.
+static bool mfma_form(int variant, MfmaForm* f) {
     switch (variant) {
-        case 8: case 9: return 8;
-        case 10: case 11: return 4;
-        default: return 0;
+        case 8: *f = {8, 4, 4}; return true;
+        case 9: case 13: *f = {8, 2, 2}; return true;
+        case 10: *f = {4, 4, 4}; return true;
+        case 11: *f = {4, 2, 2}; return true;
+        case 12: *f = {4, 4, 2}; return true;
+        default: return false;
     }
 }
 
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk) {
-    const int T = mfma_tiles(variant);
-    if (!T) return false;
-    *rows_per_block = 128u * (uint32_t)T;
+    MfmaForm f;
+    if (!mfma_form(variant, &f)) return false;
+    *rows_per_block = 128u * (uint32_t)f.tiles;
     *col_chunk = pick_col_chunk_m(fp4_rows_padded(n), *rows_per_block);
     return true;
 }
 
-template <int T, bool PF>
-static hipError_t launch_mfma_t(const AllPairsArgs& a, const void* d_img, hipStream_t s) {
+static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32_t* d_group_t) {
+    HitCtx c;
+    c.group = a.d_group;
+    c.group_t = d_group_t;
+    c.out = a.d_pairs;
+    c.cap = a.cap;
+    c.count = a.d_count;
+    c.vs = a.sink;
+    c.n = a.n;
+    c.nq = nq;
+    c.thr_full = fp4_scale2() * (256.0f - 2.0f * (float)a.max_dist);
+    c.inv_scale2 = 1.0f / fp4_scale2();
+    c.rect = rect ? 1u : 0u;
+    return c;
+}
+
+// One launch of one form. rect: rows = the nq hashes of d_img_q, columns = the a.n hashes of d_img.
+template <int T, int NBR, int S1>
+static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q, uint32_t nq,
+                              const int32_t* d_group_t, const uint32_t* d_select, uint32_t select_id, hipStream_t s) {
     const uint32_t n_pad = fp4_rows_padded(a.n);
     constexpr uint32_t ROWS = 128u * T;
-    const uint32_t chunk = pick_col_chunk_m(n_pad, ROWS);
-    dim3 grid((a.n + ROWS - 1) / ROWS, (n_pad + chunk - 1) / chunk);
-    hipLaunchKernelGGL((k_allpairs_mfma<T, PF, false>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
-                       a.d_group, a.max_dist, chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count,
-                       (const uint4*)nullptr, 0u, (const int32_t*)nullptr, fp4_scale2(), a.sink);
+    const uint32_t nrows = rect ? nq : a.n;
+    const uint64_t n_rb = (nrows + ROWS - 1) / ROWS;
+    uint64_t chunk;
+    if (!rect) {
+        chunk = pick_col_chunk_m(n_pad, ROWS);
+    } else {  // column chunk sized for the rectangle: enough tiles to fill the chip even when nq is small
+        const uint64_t want_cb = (4096 + n_rb - 1) / n_rb;
+        chunk = (n_pad + want_cb - 1) / want_cb;
+        if (chunk < 256) chunk = 256;
+        if (chunk > 4096) chunk = 4096;
+        chunk = (chunk + kSuper - 1) / kSuper * kSuper;
+        if ((n_pad + chunk - 1) / chunk > 65535u) chunk = round_up((n_pad + 65534u) / 65535u, kSuper);
+    }
+    dim3 grid((unsigned)n_rb, (unsigned)((n_pad + chunk - 1) / chunk));
+    uint32_t* buf = nullptr;
+    hipError_t e = mfma_select_buffer(&buf);
+    if (e != hipSuccess) return e;
+    HitCtx* ctx = reinterpret_cast<HitCtx*>(buf + 16);
+    hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t));
+    if (rect)
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+                           a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
+                           select_id);
+    else
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+                           a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)nullptr, fp4_scale2(), ctx, d_select,
+                           select_id);
     return hipGetLastError();
 }
 
-// Query set (nq hashes, image d_img_q) x target set (a.n hashes, image d_img_t): full rectangle.
-template <int T, bool PF>
-static hipError_t launch_cross_t(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
-                                 const int32_t* d_group_t, hipStream_t s) {
-    const uint32_t n_pad = fp4_rows_padded(a.n);
-    constexpr uint32_t ROWS = 128u * T;
-    // column chunk sized for the rectangle: enough tiles to fill the chip even when nq is small
-    uint64_t n_rb = (nq + ROWS - 1) / ROWS;
-    uint64_t want_cb = (4096 + n_rb - 1) / n_rb;
-    uint64_t chunk = (n_pad + want_cb - 1) / want_cb;
-    if (chunk < 256) chunk = 256;
-    if (chunk > 4096) chunk = 4096;
-    chunk = (chunk + kSuper - 1) / kSuper * kSuper;
-    if ((n_pad + chunk - 1) / chunk > 65535u) chunk = round_up((n_pad + 65534u) / 65535u, kSuper);
-    dim3 grid((unsigned)n_rb, (unsigned)((n_pad + chunk - 1) / chunk));
-    hipLaunchKernelGGL((k_allpairs_mfma<T, PF, true>), grid, dim3(256), 0, s, (const uint4*)d_img_t, a.n, n_pad,
-                       a.d_group, a.max_dist, (uint32_t)chunk, a.rank, a.world, a.d_pairs, a.cap, a.d_count,
-                       (const uint4*)d_img_q, nq, d_group_t, fp4_scale2(), a.sink);
-    return hipGetLastError();
+static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q,
+                                 uint32_t nq, const int32_t* d_group_t, const uint32_t* d_select, hipStream_t s) {
+    switch (variant) {
+        case 8: return launch_form<8, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 8u, s);
+        case 9: return launch_form<8, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 9u, s);
+        case 10: return launch_form<4, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 10u, s);
+        case 11: return launch_form<4, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 11u, s);
+        case 12: return launch_form<4, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 12u, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// select[0] = form to run, select[1] = survivors counted by the probe, select[2..3] spare. One per process (all
+// launches go to the one library stream).
+static uint32_t* g_select = nullptr;
+uint32_t g_mfma_auto_last[2] = {0, 0};  // for tests: not read back unless asked (hvd_debug_get)
+
+hipError_t mfma_select_buffer(uint32_t** out) {
+    if (!g_select) {
+        static_assert(sizeof(HitCtx) <= 192, "hit context does not fit its slot");
+        hipError_t e = hipMalloc((void**)&g_select, 256);  // 16 B of select words, the hit context at +64
+        if (e != hipSuccess) return e;
+    }
+    *out = g_select;
+    return hipSuccess;
+}
+
+void mfma_release() {
+    if (g_select) (void)hipFree(g_select);
+    g_select = nullptr;
+}
+
+// Probe, decide on the device, launch both candidate forms: the one the probe did not choose returns at once.
+// No host synchronisation. The DB is replicated and the probe is deterministic, so every rank of a multi-GPU
+// pass picks the same form (the tile partition depends on it).
+static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q, uint32_t nq,
+                              const int32_t* d_group_t, hipStream_t s) {
+    uint32_t* sel = nullptr;
+    hipError_t e = mfma_select_buffer(&sel);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(sel, 0, 16, s);
+    if (e != hipSuccess) return e;
+    const uint32_t nrows = rect ? nq : a.n;
+    const uint32_t rows = nrows < kProbeRows ? nrows : kProbeRows, cols = a.n < kProbeCols ? a.n : kProbeCols;
+    hipLaunchKernelGGL(k_prefilter_probe, dim3((rows + 255u) / 256u, (cols + 255u) / 256u), dim3(256), 0, s,
+                       (const uint4*)(rect ? d_img_q : d_img), nrows, (const uint4*)d_img, a.n, a.max_dist, sel);
+    hipLaunchKernelGGL(k_probe_decide, dim3(1), dim3(1), 0, s, sel, (uint64_t)rows * cols, 8192u, 9u, 12u);
+    e = launch_variant(9, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
+    if (e != hipSuccess) return e;
+    return launch_variant(12, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
+}
+
+static int effective_variant(int variant, uint32_t max_dist) {
+    // the 128-bit first stage needs 128 - 2*max_dist > 0
+    if (max_dist >= 64u) {
+        if (variant == 9 || variant == 13) return 8;
+        if (variant == 11 || variant == 12) return 10;
+    }
+    return variant;
 }
 
 hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
                              const int32_t* d_group_t, hipStream_t s) {
     if (nq == 0 || a.n == 0) return hipSuccess;
     if (a.max_dist >= 128u) return hipErrorInvalidValue;  // sign trick needs a positive threshold
-    if (a.max_dist >= 64u) return launch_cross_t<8, false>(a, d_img_q, nq, d_img_t, d_group_t, s);
-    return launch_cross_t<8, true>(a, d_img_q, nq, d_img_t, d_group_t, s);
+    const int v = effective_variant(a.variant, a.max_dist);
+    if (v == 13) return launch_auto(a, d_img_t, true, d_img_q, nq, d_group_t, s);
+    return launch_variant(v, a, d_img_t, true, d_img_q, nq, d_group_t, nullptr, s);
 }
 
 hipError_t launch_allpairs_mfma(const AllPairsArgs& a_in, const void* d_img, hipStream_t s) {
@@ -390,20 +609,15 @@ hipError_t launch_allpairs_mfma(const AllPairsArgs& a_in, const void* d_img, hip
     AllPairsArgs a = a_in;
     // The sign trick of max16_bits needs a positive threshold: 256 - 2*max_dist > 0. Larger
     // tolerances (never used by the reference, which fixes 31) go to the popcount kernel, which
-    // shares the tile geometry class; the 128-bit prefilter needs 128 - 2*max_dist > 0.
+    // shares the tile geometry class.
     if (a.max_dist >= 128u) {
-        if (!a.d_db) return hipErrorInvalidValue;
+        if (!a.d_db || a.sink.set) return hipErrorInvalidValue;
         a.variant = 0;
         return launch_allpairs(a, s);
     }
-    if (a.max_dist >= 64u && (a.variant == 9 || a.variant == 11)) a.variant -= 1;
-    switch (a.variant) {
-        case 8: return launch_mfma_t<8, false>(a, d_img, s);
-        case 9: return launch_mfma_t<8, true>(a, d_img, s);
-        case 10: return launch_mfma_t<4, false>(a, d_img, s);
-        case 11: return launch_mfma_t<4, true>(a, d_img, s);
-        default: return hipErrorInvalidValue;
-    }
+    const int v = effective_variant(a.variant, a.max_dist);
+    if (v == 13) return launch_auto(a, d_img, false, nullptr, 0u, nullptr, s);
+    return launch_variant(v, a, d_img, false, nullptr, 0u, nullptr, nullptr, s);
 }
 
 }  // namespace hvd

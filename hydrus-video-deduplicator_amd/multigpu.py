@@ -98,41 +98,45 @@ class RcclExchange:
         _lib.check(_lib.load().hvd_comm_destroy())
 
 
-class TorchDistExchange:
-    """The same exchange over an existing torch.distributed process group (gloo on CPU):
-    used by the world_size-2 CPU tests and as the bootstrap channel for the RCCL id."""
+class HostExchange:
+    """The same all-gather of candidate pairs over the control channel (hvd_amd.rendezvous, plain TCP on the
+    loopback interface): what the world_size-2 CPU tests run, and the degraded path of bench.py when the RCCL
+    bootstrap fails (reported as such in its JSON). Not used when RCCL is up."""
 
-    def __init__(self):
-        import torch.distributed as dist
-
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-
-    def broadcast_bytes(self, data: bytes | None, nbytes: int, src: int = 0) -> bytes:
-        import torch
-
-        t = torch.zeros(nbytes, dtype=torch.uint8)
-        if self.rank == src:
-            t[:] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
-        self.dist.broadcast(t, src=src)
-        return bytes(t.numpy().tobytes())
+    def __init__(self, rdzv):
+        self.rdzv = rdzv
+        self.rank, self.world = rdzv.rank, rdzv.world
 
     def allgather_pairs(self, records: np.ndarray) -> np.ndarray:
-        import torch
-
         records = np.ascontiguousarray(records, dtype=PAIR_DTYPE)
-        cnt = torch.tensor([records.size], dtype=torch.int64)
-        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
-        self.dist.all_gather(counts, cnt)
-        counts = [int(c.item()) for c in counts]
-        mx = max(counts + [1])
-        send = torch.zeros(mx * 4, dtype=torch.int32)
-        if records.size:
-            send[: records.size * 4] = torch.from_numpy(records.view(np.int32).copy())
-        recv = [torch.zeros(mx * 4, dtype=torch.int32) for _ in range(self.world)]
-        self.dist.all_gather(recv, send)
-        parts = [r.numpy()[: c * 4].copy().view(PAIR_DTYPE) for r, c in zip(recv, counts)]
+        parts = [np.frombuffer(p, dtype=PAIR_DTYPE) for p in self.rdzv.allgather(records.tobytes())]
         return np.concatenate(parts) if parts else np.zeros(0, dtype=PAIR_DTYPE)
+
+
+def connect_rccl(rdzv, timeout: float = 120.0):
+    """Collective: rank 0 creates the RCCL unique id, the control channel hands it to every rank, all ranks
+    join the communicator. ncclCommInitRank is bounded by `timeout`; the ranks then agree (min over ranks) on
+    whether RCCL is usable. -> (RcclExchange | None, reason, stuck) -- stuck = a bootstrap thread is still
+    inside RCCL and cannot be joined (the caller should leave with os._exit)."""
+    import threading
+
+    uid = rdzv.broadcast(RcclExchange.create_unique_id() if rdzv.rank == 0 else None, src=0)
+    box = {}
+
+    def _init():
+        try:
+            box["ex"] = RcclExchange(rdzv.rank, rdzv.world, uid)
+        except Exception as exc:  # noqa: BLE001 - reported to the caller
+            box["err"] = exc
+
+    th = threading.Thread(target=_init, daemon=True)
+    th.start()
+    th.join(timeout=timeout)
+    ok = 1.0 if ("ex" in box and not th.is_alive()) else 0.0
+    if rdzv.allreduce_min([ok])[0] >= 1.0:
+        return box["ex"], "rccl", False
+    why = "timed out" if th.is_alive() else repr(box.get("err", "failed on another rank"))
+    return None, why, th.is_alive()
 
 
 def launch_allpairs(lib, d_db_ptr: int, d_img_ptr: int | None, n: int, d_group_ptr, max_dist: int, rank: int,

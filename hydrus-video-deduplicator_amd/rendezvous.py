@@ -1,0 +1,171 @@
+"""Rendezvous of the ranks of ONE node without PyTorch: a star of TCP connections on the loopback
+interface, used for the 128-byte RCCL unique id, barriers and the max-over-ranks of timings.
+
+The data path never goes through here: candidate pairs, video-level keys and hash shards are
+exchanged by RCCL over xGMI inside the C-ABI (`hvd_comm_*`). This is the control channel only, so
+plain sockets are enough -- and they keep `torch` out of the product (north_star: "no PyTorch").
+
+Rank 0 listens on an ephemeral loopback port and publishes it in a file that all ranks can
+derive: ``$HVD_RDZV_FILE`` or ``/tmp/hvd_rdzv_<MASTER_PORT>_<parent pid>`` -- the workers that
+`python -m torch.distributed.run` (or any other launcher) starts share their parent process, and
+MASTER_PORT distinguishes concurrent launches. Every collective is one round trip through rank 0.
+"""
+
+from __future__ import annotations
+
+import os
+import socket
+import struct
+import tempfile
+import time
+
+_MAGIC = b"HVDRDZV1"
+
+
+def _default_file() -> str:
+    explicit = os.environ.get("HVD_RDZV_FILE")
+    if explicit:
+        return explicit
+    return os.path.join(tempfile.gettempdir(), f"hvd_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytes:
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _send_msg(sock: socket.socket, payload: bytes) -> None:
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_msg(sock: socket.socket) -> bytes:
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class Rendezvous:
+    """rank/world default to $RANK / $WORLD_SIZE. world == 1 needs no sockets at all."""
+
+    def __init__(self, rank: int | None = None, world: int | None = None, path: str | None = None, timeout: float = 300.0):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self.timeout = timeout
+        self.path = path or _default_file()
+        self._peers: list[socket.socket | None] = []
+        self._up: socket.socket | None = None
+        self._listener: socket.socket | None = None
+        if self.world > 1:
+            if self.rank == 0:
+                self._serve()
+            else:
+                self._connect()
+
+    # ---- set-up -------------------------------------------------------------------------
+    def _serve(self) -> None:
+        try:
+            os.unlink(self.path)  # a stale file of an earlier launch must not be believed
+        except FileNotFoundError:
+            pass
+        ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        ls.bind(("127.0.0.1", 0))
+        ls.listen(self.world)
+        ls.settimeout(self.timeout)
+        self._listener = ls
+        tmp = f"{self.path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            f.write(str(ls.getsockname()[1]))
+        os.replace(tmp, self.path)  # atomic: readers see nothing or the whole port number
+        peers: list[socket.socket | None] = [None] * self.world
+        deadline = time.monotonic() + self.timeout
+        while any(p is None for p in peers[1:]):
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rendezvous: {sum(p is None for p in peers[1:])} rank(s) never connected")
+            conn, _ = ls.accept()
+            conn.settimeout(self.timeout)
+            try:
+                hello = _recv_exact(conn, len(_MAGIC) + 8)
+            except (ConnectionError, socket.timeout):
+                conn.close()
+                continue
+            r, w = struct.unpack("<II", hello[len(_MAGIC):])
+            if hello[: len(_MAGIC)] != _MAGIC or w != self.world or not (0 < r < self.world) or peers[r] is not None:
+                conn.close()
+                continue
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            conn.sendall(_MAGIC)
+            peers[r] = conn
+        self._peers = peers
+
+    def _connect(self) -> None:
+        deadline = time.monotonic() + self.timeout
+        last = None
+        while time.monotonic() < deadline:
+            try:
+                port = int(open(self.path).read().strip())
+                s = socket.create_connection(("127.0.0.1", port), timeout=5.0)
+                s.settimeout(self.timeout)
+                s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                s.sendall(_MAGIC + struct.pack("<II", self.rank, self.world))
+                if _recv_exact(s, len(_MAGIC)) == _MAGIC:
+                    self._up = s
+                    return
+                s.close()
+            except (OSError, ValueError, ConnectionError) as exc:  # not published yet / stale file / refused
+                last = exc
+            time.sleep(0.05)
+        raise TimeoutError(f"rendezvous: rank {self.rank} could not reach rank 0 via {self.path}: {last!r}")
+
+    # ---- collectives (all of them: gather at rank 0, then fan out) ---------------------------
+    def allgather(self, data: bytes) -> list[bytes]:
+        if self.world == 1:
+            return [bytes(data)]
+        if self.rank == 0:
+            parts = [bytes(data)] + [_recv_msg(p) for p in self._peers[1:]]
+            blob = b"".join(struct.pack("<Q", len(x)) + x for x in parts)
+            for p in self._peers[1:]:
+                _send_msg(p, blob)
+            return parts
+        _send_msg(self._up, bytes(data))
+        blob = _recv_msg(self._up)
+        parts, pos = [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from("<Q", blob, pos)
+            parts.append(blob[pos + 8: pos + 8 + n])
+            pos += 8 + n
+        return parts
+
+    def barrier(self) -> None:
+        self.allgather(b"")
+
+    def broadcast(self, data: bytes | None, src: int = 0) -> bytes:
+        return self.allgather(bytes(data) if self.rank == src else b"")[src]
+
+    def allreduce_max(self, values) -> list[float]:
+        vals = [float(v) for v in values]
+        parts = self.allgather(struct.pack(f"<{len(vals)}d", *vals))
+        cols = [struct.unpack(f"<{len(vals)}d", p) for p in parts]
+        return [max(c[k] for c in cols) for k in range(len(vals))]
+
+    def allreduce_min(self, values) -> list[float]:
+        return [-v for v in self.allreduce_max([-float(x) for x in values])]
+
+    def close(self) -> None:
+        for s in [self._up, self._listener, *self._peers]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._up = self._listener = None
+        self._peers = []
+        if self.rank == 0 and self.world > 1:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass

@@ -19,7 +19,7 @@ from . import _lib, vpdq
 from ._lib import PAIR_DTYPE, VMATCH_DTYPE
 
 DISTANCE_TOLERANCE = 31  # per-frame Hamming tolerance (vpdqpy/vpdqpy.py:53, db/vptree.py:31)
-DEFAULT_VARIANT = 9  # all-pairs kernel the product uses (FP4-MFMA + exact 128-bit prefilter); DESIGN.md 4.1
+DEFAULT_VARIANT = 13  # all-pairs kernel the product uses (FP4-MFMA, 128-bit first stage, form chosen by a probe); DESIGN.md 4.1
 
 
 def fix_vpdq_similarity(similarity: float) -> int:

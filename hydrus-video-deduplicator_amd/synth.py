@@ -116,3 +116,24 @@ def video_hashes(num_videos: int, seed: int = 5, frames_per_video=64, copy_fract
             frames[offsets[d] : offsets[d] + ncopy] = flip_bits(frames[offsets[s] : offsets[s] + ncopy], k, rng)
             planted.append((s, int(d)))
     return frames, offsets, np.array(planted, dtype=np.int64).reshape(-1, 2)
+
+
+def hash_db_clustered(n: int, n_clusters: int, cluster_size: int, seed: int = 8, max_flips: int = 8):
+    """uint8[n,32] uniform random hashes in which n_clusters * cluster_size rows, scattered uniformly over the DB,
+    form clusters of near-identical hashes (a random centre with k~U{0..max_flips} bit flips per member, so all
+    members of a cluster are within 2*max_flips of each other): the regime of real frame hashes (static scenes,
+    re-encodes), where many panels of the all-pairs kernel contain a hit. Returns (db, members int64[n_clusters,
+    cluster_size]); the exact pair count is n_clusters * C(cluster_size, 2) when 2*max_flips <= tolerance."""
+    rng = _rng(seed)
+    db = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    m = n_clusters * cluster_size
+    if m > n:
+        raise ValueError("clusters do not fit in the DB")
+    pos = rng.choice(n, size=m, replace=False).astype(np.int64)
+    centres = rng.integers(0, 256, (n_clusters, 32), dtype=np.uint8)
+    rows = np.repeat(centres, cluster_size, axis=0)
+    chunk = 1 << 16
+    for c0 in range(0, m, chunk):
+        sl = slice(c0, min(m, c0 + chunk))
+        db[pos[sl]] = flip_bits(rows[sl], rng.integers(0, max_flips + 1, rows[sl].shape[0]), rng)
+    return db, pos.reshape(n_clusters, cluster_size)

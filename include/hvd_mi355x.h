@@ -40,7 +40,9 @@ extern "C" {
 #define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
 #define HVD_UNIQUE_ID_BYTES 128
 #define HVD_ABI_VERSION 2
-#define HVD_DEFAULT_VARIANT 9 /* all-pairs kernel the host entry points use: FP4-MFMA + 128-bit prefilter */
+/* All-pairs kernel the host entry points use: FP4-MFMA with a 128-bit first stage; which of its two forms runs
+ * (survivors fetch their other half | second stage out of registers) is chosen per launch from a probe of the data. */
+#define HVD_DEFAULT_VARIANT 13
 
 typedef struct {
     uint32_t i, j, dist, pad;
@@ -142,6 +144,8 @@ int hvd_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int hvd_memcpy_d2h(void* dst, const void* d_src, size_t bytes);
 int hvd_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes); /* enqueued on the library stream */
 int hvd_dev_sync(void);
+/* hipDeviceSynchronize(): every stream of the bound device (the library stream, the hashers' streams, RCCL's). */
+int hvd_device_synchronize(void);
 
 /* DCT accumulation mode of the frame hash. HVD_DCT_STRICT (default): every `sum += D*A` is a
  * separately rounded multiply and add -- the numerics of upstream's x86-64 builds and of the
@@ -164,6 +168,9 @@ int hvd_get_pdq_dct_mode(void);
  *   "vmatch_slots_log2" 0|4..30                            (initial size of the video-reduction tables; tests the regrowth)
  * Unknown keys and out-of-range values return HVD_ERR_ARG. */
 int hvd_debug_set(const char* key, int value);
+/* "mfma_auto_form": the form (9 or 12) the last variant-13 launch ran; "mfma_probe_survivors": what its probe counted.
+ * Synchronises the library stream. */
+int hvd_debug_get(const char* key, int* out_value);
 
 /* Bytes of device scratch hvd_dev_pdq_hash_frames needs for this geometry (0 for
  * 64x64 gray): the 64x64 float luma of every frame plus the blur workspace. */

@@ -241,9 +241,9 @@ def _run_variant(gpu, hvd, db, variant, max_dist=31, group=None, cap=1 << 16):
     return hvd.multigpu.merge_pairs([d_pairs.to_array(gpu.PAIR_DTYPE, cnt)])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13])
 def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
-    """Popcount (0..6) and FP4-MFMA (8..11) forms produce the identical pair list."""
+    """Popcount (0..6) and FP4-MFMA (8..13) forms produce the identical pair list."""
     n = 20000
     db, _ = hvd.synth.hash_db(n, seed=53, plant_fraction=0.01)
     want = oracle.allpairs(db, 31, num_threads=8)
@@ -252,7 +252,7 @@ def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
     assert np.array_equal(_run_variant(gpu, hvd, db, variant, group=grp), oracle.allpairs(db, 31, group=grp, num_threads=8))
 
 
-@pytest.mark.parametrize("variant", [8, 9])
+@pytest.mark.parametrize("variant", [8, 9, 12, 13])
 @pytest.mark.parametrize("max_dist", [0, 31, 63, 64, 127, 128, 256])
 def test_k2_mfma_threshold_routing(gpu, hvd, oracle, variant, max_dist):
     """dot >= 256-2*max_dist is the popcount predicate for every tolerance, including the ones

@@ -365,3 +365,45 @@ def test_config5_chained_full_size(gpu, hvd, oracle):
     assert checksum == r1["checksum"] and len(pairs) == r1["pairs"]
     d_frames.free()
     d_copy.free()
+
+
+# ------------------------------------------------------------------ K2: data-dependent kernel form --------
+
+def _auto_form(gpu):
+    v = C.c_int(0)
+    gpu.check(gpu.load().hvd_debug_get(b"mfma_auto_form", C.byref(v)))
+    s = C.c_int(0)
+    gpu.check(gpu.load().hvd_debug_get(b"mfma_probe_survivors", C.byref(s)))
+    return v.value, s.value
+
+
+def test_k2_auto_variant_picks_the_form_from_the_data(gpu, hvd, oracle):
+    """Variant 13 probes how often the first 128 bits of unrelated hashes agree and runs the fetch form (9) on uniform
+    hashes, the register form (12) on structured ones; the pair list is the oracle's either way."""
+    n = 30000
+    uni, _ = hvd.synth.hash_db(n, seed=93, plant_fraction=0.01)
+    assert np.array_equal(hvd.allpairs_hamming(uni, 31), oracle.allpairs(uni, 31, num_threads=8))
+    form, surv = _auto_form(gpu)
+    assert form == 9, (form, surv)
+    # structured: the first 128 bits come from 64 prototypes, the last 128 bits are random -> the 128-bit first stage
+    # passes 1/64 of all pairs, none of which is a hit
+    rng = np.random.default_rng(94)
+    proto = rng.integers(0, 256, (64, 16), dtype=np.uint8)
+    st = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    st[:, :16] = proto[rng.integers(0, 64, n)]
+    st[5000] = st[17]  # and a few real duplicates
+    st[20000, :] = st[123, :]
+    st[20000, 31] ^= 0x0F
+    want = oracle.allpairs(st, 31, num_threads=8)
+    assert len(want) >= 2
+    assert np.array_equal(hvd.allpairs_hamming(st, 31), want)
+    form, surv = _auto_form(gpu)
+    assert form == 12 and surv > 1000, (form, surv)
+    # every explicit form agrees on the structured DB too (the fetch forms go through their survivor path all the time)
+    from test_gpu_parity import _run_variant
+
+    for v in (8, 9, 10, 11, 12):
+        assert np.array_equal(_run_variant(gpu, hvd, st, v), want), v
+    # video mode on structured frames
+    off = np.arange(0, n + 1, 30, dtype=np.int64)
+    assert np.array_equal(hvd.match_videos(st, off, 31), oracle.match_videos(st, off, 31))
