@@ -333,19 +333,29 @@ def main():
     cmp_per_launch = total_cmp / world
     achieved = cmp_per_launch * BYTES_PER_COMPARISON / (kernel_avg_ms * 1e-3) / 1e9
     traffic = load_traffic(f"allpairs_n{n}_v{variant}_w{world}")
+    if traffic is None and variant == 13:
+        traffic = load_traffic(f"allpairs_n{n}_v9_w{world}")
     hbm_equiv = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(achieved / HBM_PEAK_GBS, 3),
                  "note": "SURVEY.md 8d accounting: 64 B per comparison with no operand reuse credited; frac > 1 "
                          "because tiles re-use operands from registers/LDS"}
+    form = variant
+    if variant == 13:  # which of its two forms did the probe choose for this DB?
+        fv = C.c_int(0)
+        L.check(lib.hvd_debug_get(b"mfma_auto_form", C.byref(fv)))
+        form = fv.value
     if variant >= 8:
-        # executed matrix work: 2 (prefilter) or 4 MFMAs of 2*32*32*64 flop per 1024 comparisons
-        flop_per_cmp = 256.0 if variant in (9, 11) else 512.0
+        # executed matrix work: 2 (128-bit first stage) or 4 MFMAs of 2*32*32*64 flop per 1024 comparisons
+        flop_per_cmp = 256.0 if form in (9, 11, 12) else 512.0
         tfl = cmp_per_launch * flop_per_cmp / (kernel_avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": f"k_allpairs_mfma(variant={variant})", "achieved": round(tfl, 1),
+        roofline = {"bound": "mfma", "kernel": f"k_allpairs_mfma(variant={variant}" + (f" -> form {form} chosen by the probe)" if variant == 13 else ")"),
+                    "achieved": round(tfl, 1),
                     "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / FP4_PEAK_TFLOPS, 3),
                     "traffic": traffic, "kernel_ms": round(kernel_avg_ms, 3), "kernel_ms_sd_rank0": round(k_sd, 3),
                     "instr": "v_mfma_f32_32x32x64_f8f6f4 cbsz:4 blgp:4 on the +-1 FP4 image of the hashes",
-                    "flop_per_comparison_executed": flop_per_cmp, "hbm_equivalent": hbm_equiv}
+                    "flop_per_comparison_executed": flop_per_cmp, "hbm_equivalent": hbm_equiv,
+                    "note": "kernel_ms covers everything between the HIP events of one pass: probe + form selection + the "
+                            "all-pairs kernel; `achieved` counts only the first-stage MFMAs every comparison executes"}
     else:
         roofline = {"bound": "hbm", "kernel": f"k_allpairs(variant={variant})", "traffic": traffic,
                     "kernel_ms": round(kernel_avg_ms, 3), **hbm_equiv,
@@ -421,8 +431,8 @@ def main():
             return mean_sd(ks) + (int(d_cnt.to_array(np.uint64, 1)[0]),)
 
         # every exact form next to the default, for transparency (same DB, same launch shape)
-        for v, name in ((0, "popcount_full_16op"), (1, "popcount_prefilter128"), (8, "mfma_fp4_full"),
-                        (9, "mfma_fp4_prefilter128")):
+        for v, name in ((0, "popcount_full_16op"), (1, "popcount_prefilter128"), (8, "mfma_fp4_full_256"),
+                        (9, "mfma_fp4_stage128_fetch"), (12, "mfma_fp4_stage128_registers")):
             mu, sd, _ = time_variant(v, reps=3)
             extra[name] = {"kernel_ms": round(mu, 3), "kernel_ms_sd": round(sd, 3), "comparisons_per_s": sig(total_cmp / (mu * 1e-3))}
         out["kernel_variants"] = extra
@@ -445,7 +455,12 @@ def main():
             clustered[name] = {"kernel_ms": round(mu, 3), "kernel_ms_sd": round(sd, 3),
                                "comparisons_per_s": sig(total_cmp / (mu * 1e-3)), "pairs": cnt,
                                "slow_path_share_of_panels": round(1.0 - math.exp(-8192 * p_pair), 3),
-                               "vs_uniform": round(extra["mfma_fp4_prefilter128"]["kernel_ms"] / mu, 3) if variant == 9 else None}
+                               "form": None,
+                               "vs_uniform": round(k_mean / mu, 3)}
+            if variant == 13:
+                fv = C.c_int(0)
+                L.check(lib.hvd_debug_get(b"mfma_auto_form", C.byref(fv)))
+                clustered[name]["form"] = fv.value
             d_dbc.free()
             d_imgc.free()
             del dbc

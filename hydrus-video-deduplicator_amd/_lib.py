@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhvd_mi355x.so")
+LIB_PATH = os.environ.get("HVD_LIB_PATH") or os.path.join(_HERE, "libhvd_mi355x.so")  # override: A/B builds
 
 HVD_OK = 0
 HVD_ERR_ARG = -1

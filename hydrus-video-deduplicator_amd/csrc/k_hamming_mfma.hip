@@ -82,6 +82,33 @@ __device__ __forceinline__ int max16_bits(const v16f& c) {
     return max(m0, m3);
 }
 
+// The fast path's form of the same test. The query fragments are NEGATED (+-1 -> -+1: one XOR of the sign nibbles at
+// load) and the accumulator starts at (threshold - 1): acc = (thr - 1) - dot. Dot products of +-1 vectors of even
+// length are even, so acc is an odd multiple of the scale -- never 0 -- and NEGATIVE exactly when dot >= thr: a hit is
+// a set sign bit, and "any of these 16" is the sign of their bitwise OR. v_or3_b32 issues at the full VALU rate where
+// v_max3_i32 takes two slots (profiles/r01_ubench_valu.txt), and the epilogue is what the power-limited clock pays for.
+__device__ __forceinline__ int or16_bits(const v16f& c) {
+    int m0 = __float_as_int(c[0]) | __float_as_int(c[1]) | __float_as_int(c[2]);
+    int m1 = __float_as_int(c[3]) | __float_as_int(c[4]) | __float_as_int(c[5]);
+    int m2 = __float_as_int(c[6]) | __float_as_int(c[7]) | __float_as_int(c[8]);
+    int m3 = __float_as_int(c[9]) | __float_as_int(c[10]) | __float_as_int(c[11]);
+    int m4 = __float_as_int(c[12]) | __float_as_int(c[13]) | __float_as_int(c[14]);
+    m0 = m0 | m1 | m2;
+    m3 = m3 | m4 | __float_as_int(c[15]);
+    return m0 | m3;
+}
+
+__device__ __forceinline__ float min16(const v16f& c) {
+    float m0 = fminf(fminf(c[0], c[1]), c[2]);
+    float m1 = fminf(fminf(c[3], c[4]), c[5]);
+    float m2 = fminf(fminf(c[6], c[7]), c[8]);
+    float m3 = fminf(fminf(c[9], c[10]), c[11]);
+    float m4 = fminf(fminf(c[12], c[13]), c[14]);
+    m0 = fminf(fminf(m0, m1), m2);
+    m3 = fminf(fminf(m3, m4), c[15]);
+    return fminf(m0, m3);
+}
+
 __device__ __forceinline__ void append_pair_m(hvd_pair* out, unsigned long long cap, unsigned long long* count,
                                               uint32_t i, uint32_t j, uint32_t dist) {
     unsigned long long slot = atomicAdd(count, 1ull);
@@ -94,6 +121,11 @@ __device__ __forceinline__ void append_pair_m(hvd_pair* out, unsigned long long 
         out[slot] = p;
     }
 }
+
+#ifndef HVD_K2_SIGN
+#define HVD_K2_SIGN 1  // 1: threshold folded into negated accumulators, OR-reduction (or16_bits); 0: plain dot, max-reduction
+#endif
+constexpr bool kSign = HVD_K2_SIGN != 0;
 
 constexpr int kSuper = 128;  // candidates per LDS super-panel (256: -4 % with the prefilter, +2 % without)
 
@@ -118,6 +150,7 @@ struct HitCtx {
     uint32_t n, nq;
     float thr_full, inv_scale2;
     uint32_t rect;
+    float acc_start;  // start value of the launched form's accumulators (see or16_bits)
 };
 
 // Hits of one 32x32 tile whose accumulators hold the full 256-bit dot products: acc[r] belongs to
@@ -135,18 +168,29 @@ struct HitCtx {
 // A pointer argument of a non-kernel function arrives in VGPRs; make it provably uniform and constant so that the
 // context is fetched with scalar loads into SGPRs (as flat loads it occupied ~30 VGPRs, which add to the fast path's
 // register footprint: the handlers' registers and the values their caller keeps live across the call must coexist).
+// (readfirstlane returns a SIGNED int: widen through uint32_t, or a low dword with bit 31 set smears into the high one)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+#else
+    return v;
+#endif
+}
+
 __device__ __forceinline__ HitCtx load_ctx(const HitCtx* ctx) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long praw = (unsigned long long)ctx;
-    const unsigned long long puni = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(praw >> 32)) << 32) |
-                                    (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)praw);
-    return *(const __attribute__((address_space(4))) HitCtx*)puni;
+    return *(const __attribute__((address_space(4))) HitCtx*)uniform_u64((unsigned long long)ctx);
 #else
     return *ctx;
 #endif
 }
 
-__device__ __forceinline__ void tile_hits_body(const v16f& acc, uint32_t row0, uint32_t j, uint32_t lane, const HitCtx& c) {
+// acc holds sgn * dot + off (sgn = +1, off = 0 for a plain recomputation; sgn = -1, off = start value for the fast
+// path's negated accumulators): dot = sgn * (acc - off) ... written as one exact fma on small integers.
+__device__ __forceinline__ void tile_hits_body(const v16f& acc, uint32_t row0, uint32_t j, uint32_t lane, const HitCtx& c,
+                                               float sgn, float off) {
     const uint32_t li = lane & 31u, h = lane >> 5;
     const bool video = c.vs.set != nullptr;
     const bool rect = c.rect != 0u;
@@ -167,10 +211,11 @@ __device__ __forceinline__ void tile_hits_body(const v16f& acc, uint32_t row0, u
 #pragma unroll 1
     for (int r = 0; r < 16; ++r) {
         const uint32_t i = row0 + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * h;
-        bool ok = acc[r] >= c.thr_full && j < c.n && (rect ? i < c.nq : i < j);
+        const float dot = fmaf(sgn, acc[r], -sgn * off);
+        bool ok = dot >= c.thr_full && j < c.n && (rect ? i < c.nq : i < j);
         if (ok && c.group != nullptr) ok = c.group[i] != gcol;
         if (!video) {
-            if (ok) append_pair_m(c.out, c.cap, c.count, i, j, (uint32_t)(256 - (int)(acc[r] * c.inv_scale2)) >> 1);
+            if (ok) append_pair_m(c.out, c.cap, c.count, i, j, (uint32_t)(256 - (int)(dot * c.inv_scale2)) >> 1);
             continue;
         }
         const unsigned long long rowhits = __ballot(ok);
@@ -187,10 +232,12 @@ __device__ __forceinline__ void tile_hits_body(const v16f& acc, uint32_t row0, u
     }
 }
 
+// NEG: the accumulators are the fast path's negated ones (start value c.acc_start); otherwise plain dot products.
+template <bool NEG>
 __device__ __noinline__ void tile_hits(const v16f acc, uint32_t row0, uint32_t j, uint32_t lane,
                                        const HitCtx* __restrict__ ctx) {
     const HitCtx c = load_ctx(ctx);
-    tile_hits_body(acc, row0, j, lane, c);
+    tile_hits_body(acc, row0, j, lane, c, NEG ? -1.0f : 1.0f, NEG ? c.acc_start : 0.0f);
 }
 
 // Deferred form of the same for the kernels whose query fragments hold only the first 128 bits: `flagged` has one bit
@@ -198,14 +245,27 @@ __device__ __noinline__ void tile_hits(const v16f acc, uint32_t row0, uint32_t j
 // recomputed over all 256 bits, one k-step at a time straight from memory (few registers: see load_ctx), and their
 // hits reported.
 template <int TILES>
-__device__ __noinline__ void panel_survivors(uint32_t flagged, const uint4* __restrict__ imgq, const uint4* base, uint32_t sw,
-                                             uint32_t wrow0, uint32_t j, uint32_t lane, const HitCtx* __restrict__ ctx) {
-    const HitCtx c = load_ctx(ctx);
-    const uint32_t li = lane & 31u, h = lane >> 5;
-    const int thr2_bits = __float_as_int(c.thr_full);
+__device__ __noinline__ void panel_survivors(uint32_t flagged_v, const uint4* __restrict__ imgq_v, const uint4* panel_v,
+                                             uint32_t wrow0_v, uint32_t j0_v, uint32_t lane, const HitCtx* __restrict__ ctx) {
+    // Everything but the lane id is wave-uniform; arguments of a non-kernel function arrive in VGPRs, so move them to
+    // SGPRs: what stays live across the nested handler call below adds to the fast path's register footprint.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t flagged = (uint32_t)__builtin_amdgcn_readfirstlane((int)flagged_v);
+    const uint32_t wrow0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wrow0_v);
+    const uint32_t j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0_v);
+#else
+    const uint32_t flagged = flagged_v, wrow0 = wrow0_v, j0 = j0_v;
+#endif
+    const uint4* __restrict__ imgq = (const uint4*)uniform_u64((unsigned long long)imgq_v);
+    const uint4* panel = (const uint4*)uniform_u64((unsigned long long)panel_v);
+    const int thr2_bits = __float_as_int(load_ctx(ctx).thr_full);
 #pragma unroll 1
     for (int t = 0; t < TILES; ++t) {
         if (!((flagged >> t) & 1u)) continue;  // wave-uniform
+        const uint32_t li = lane & 31u, h = lane >> 5;
+        const uint32_t cl = (j0 & (uint32_t)(kSuper - 1)) + li;  // candidate index inside the super-panel
+        const uint4* base = &panel[cl * 8u];
+        const uint32_t sw = (cl >> 1) & 7u;
         const uint32_t hash = wrow0 + 32u * (uint32_t)t + li;
         v16f acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 1
@@ -215,7 +275,8 @@ __device__ __noinline__ void panel_survivors(uint32_t flagged, const uint4* __re
             acc = mfma_fp4(af, bf, acc);
         }
         if (!__any(max16_bits(acc) >= thr2_bits)) continue;
-        tile_hits_body(acc, wrow0 + 32u * (uint32_t)t, j, lane, c);
+        // (a nested call on purpose: this function's own footprint stays small)
+        tile_hits<false>(acc, wrow0 + 32u * (uint32_t)t, j0 + li, lane, ctx);
     }
 }
 
@@ -282,19 +343,29 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     for (int t = 0; t < TILES; ++t) {
         const uint32_t hash = wrow0 + 32u * t + li;  // < n_pad by construction
 #pragma unroll
-        for (int s = 0; s < NBR; ++s) a[t][s] = as_v4i(imgq[(size_t)hash * 8u + img_slot(hash, 2u * s + h)]);
+        for (int s = 0; s < NBR; ++s) {
+            const uint4 q = imgq[(size_t)hash * 8u + img_slot(hash, 2u * s + h)];
+            // negated: flip the sign bit of every e2m1 nibble (see or16_bits)
+            const uint32_t fl = kSign ? 0x88888888u : 0u;
+            a[t][s] = v4i{(int)(q.x ^ fl), (int)(q.y ^ fl), (int)(q.z ^ fl), (int)(q.w ^ fl)};
+        }
     }
 
-    // every product is +-v*v = +-scale2, so all dot products (and thresholds) scale by scale2
-    const float thr_full = scale2 * (256.0f - 2.0f * (float)max_dist);                     // > 0 (host guarantees)
-    const float thr_fast = S1 == 2 ? scale2 * (128.0f - 2.0f * (float)max_dist) : thr_full;  // > 0 (host guarantees)
-    const int thr1_bits = __float_as_int(thr_fast), thr2_bits = __float_as_int(thr_full);
+    // every product is +-v*v = +-scale2, so all dot products (and thresholds) scale by scale2.
+    // first stage: acc = c1 - dot over 64*S1 bits, hit candidate <=> acc < 0; the second stage of the register forms
+    // goes on to acc = c1 - dot256, a hit <=> dot256 >= 256 - 2*max_dist <=> acc <= c1 - thr_full = -129*scale2 (S1 = 2)
+    const float c1 = kSign ? scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist - 1.0f) : 0.0f;
+    const float hit2 = -128.5f * scale2;
+    const int thr1_bits = __float_as_int(scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist));  // plain form
+    const int thr2_bits = __float_as_int(scale2 * (256.0f - 2.0f * (float)max_dist));
+    auto stage1_hit = [&](const v16f& acc) { return kSign ? __any(or16_bits(acc) < 0) : __any(max16_bits(acc) >= thr1_bits); };
+    auto stage2_hit = [&](const v16f& acc) { return kSign ? __any(min16(acc) < hit2) : __any(max16_bits(acc) >= thr2_bits); };
 
     // candidates <= row0 cannot pair with rows >= row0 (i<j): start at the super-panel holding row0+1
     const uint32_t j0 = RECT ? col0 : max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
     const uint32_t nsp = (col1 - j0) / kSuper;  // col0, col1, j0 are multiples of kSuper
 
-    const v16f zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const v16f zero = {c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1};  // the accumulators' start value
 
     // The two LDS buffers are separate objects and the super-panel loop is unrolled by two, so that every
     // ds_read names one array and every in-flight global->LDS load the other: with one two-dimensional array
@@ -320,11 +391,11 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
 #pragma unroll
                 for (int t = 1; t < TILES; ++t) {
                     const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
-                    flagged |= __any(max16_bits(cur) >= thr1_bits) ? (1u << (t - 1)) : 0u;
+                    flagged |= stage1_hit(cur) ? (1u << (t - 1)) : 0u;
                     cur = nxt;
                 }
-                flagged |= __any(max16_bits(cur) >= thr1_bits) ? (1u << (TILES - 1)) : 0u;
-                if (__builtin_expect(flagged != 0u, 0)) panel_survivors<TILES>(flagged, imgq, base, sw, wrow0, jsp + cl, lane, ctx);
+                flagged |= stage1_hit(cur) ? (1u << (TILES - 1)) : 0u;
+                if (__builtin_expect(flagged != 0u, 0)) panel_survivors<TILES>(flagged, imgq, panel, wrow0, jsp + 32u * p, lane, ctx);
             } else {
                 // each tile is judged on its own: a survivor's second stage runs out of registers at once, and only a
                 // tile with a real hit (all 256 bits) calls the handler
@@ -334,18 +405,18 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
 #pragma unroll
                         for (int s = 0; s < 2; ++s) b2[s] = as_v4i(base[(2u * (s + 2) + h) ^ sw]);
                         acc = tile_dot<0, 2>(&a[t][2], b2, acc);
-                        if (!__any(max16_bits(acc) >= thr2_bits)) return;
+                        if (!stage2_hit(acc)) return;
                     }
-                    tile_hits(acc, wrow0 + 32u * (uint32_t)t, jsp + cl, lane, ctx);
+                    tile_hits<kSign>(acc, wrow0 + 32u * (uint32_t)t, jsp + cl, lane, ctx);
                 };
                 v16f cur = tile_dot<0, S1>(a[0], b, zero);
 #pragma unroll
                 for (int t = 1; t < TILES; ++t) {
                     const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
-                    if (__builtin_expect(__any(max16_bits(cur) >= thr1_bits), 0)) survivor(t - 1, cur);
+                    if (__builtin_expect(stage1_hit(cur), 0)) survivor(t - 1, cur);
                     cur = nxt;
                 }
-                if (__builtin_expect(__any(max16_bits(cur) >= thr1_bits), 0)) survivor(TILES - 1, cur);
+                if (__builtin_expect(stage1_hit(cur), 0)) survivor(TILES - 1, cur);
             }
         }
     };
@@ -482,7 +553,7 @@ bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, u
     return true;
 }
 
-static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32_t* d_group_t) {
+static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32_t* d_group_t, int s1) {
     HitCtx c;
     c.group = a.d_group;
     c.group_t = d_group_t;
@@ -495,6 +566,7 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
     c.thr_full = fp4_scale2() * (256.0f - 2.0f * (float)a.max_dist);
     c.inv_scale2 = 1.0f / fp4_scale2();
     c.rect = rect ? 1u : 0u;
+    c.acc_start = fp4_scale2() * ((float)(64 * s1) - 2.0f * (float)a.max_dist - 1.0f);
     return c;
 }
 
@@ -522,7 +594,7 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
     hipError_t e = mfma_select_buffer(&buf);
     if (e != hipSuccess) return e;
     HitCtx* ctx = reinterpret_cast<HitCtx*>(buf + 16);
-    hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t));
+    hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1));
     if (rect)
         hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
