@@ -6,7 +6,7 @@ The directory name has hyphens; import it as ``hvd_amd`` (see /hvd_amd.py).
 """
 
 from . import (_lib, hashing, multigpu, pipeline, rendezvous, search, sqlite_adapter, synth, vpdq,  # noqa: F401
-               vpdqpy)
+               vpdqpy, vptree)
 from .hashing import compute_phash, decode_phash_from_str, encode_phash_to_str, get_phash_similarity  # noqa: F401
 from .search import (allpairs_hamming, calculate_distance, find_potential_duplicates,  # noqa: F401
                      fix_vpdq_similarity, match_videos)

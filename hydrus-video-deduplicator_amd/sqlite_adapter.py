@@ -5,7 +5,11 @@ Schema (reference db/DedupeDB.py:153-189):
     shape_perceptual_hashes(phash_id PK, phash BLOB UNIQUE)        -- N x 32 bytes, db/DedupeDB.py:535-559
     shape_perceptual_hash_map(phash_id, hash_id)                   -- one phash per file; files may share one
     shape_search_cache(hash_id PK, searched_distance)              -- NULL / < threshold => still to search
-    phashed_file_queue(file_hash, phash)                           -- hashed, not yet inserted
+    phashed_file_queue(file_hash, phash)                           -- hashed, not yet inserted: ingest_phashed_file_queue()
+
+Databases written before 0.10.0 hold every perceptual hash as JSON text (one "hex,quality,frame" string per
+frame, bytes in reverse order, low-quality frames still present): `convert_old_vpdq_to_new` /
+`upgrade_old_phashes` apply the reference's own migration (db/DedupeDB.py:528-584) instead of failing.
 
 This replaces HydrusVideoDeduplicator.find_potential_duplicates (dedup.py:445-502) without the
 VP-tree: every file whose `searched_distance` is NULL or below the search threshold is searched
@@ -23,6 +27,79 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import search
+
+QUALITY_TOLERANCE = 31  # db/DedupeDB.py:550-553
+
+
+def convert_old_vpdq_to_new(old_vpdq_phash_json) -> bytes:
+    """A pre-0.10.0 perceptual hash (JSON list of "<64 hex>,<quality>,<frame number>") in today's format: the
+    frames with quality >= 31 in order, each hash with its 32 bytes reversed (db/DedupeDB.py:535-559)."""
+    import json
+
+    if isinstance(old_vpdq_phash_json, (bytes, bytearray, memoryview)):
+        old_vpdq_phash_json = bytes(old_vpdq_phash_json).decode("ascii")
+    out = bytearray()
+    for feature in json.loads(old_vpdq_phash_json):
+        hex_hash, quality, _frame_number = feature.split(",")
+        if int(quality) >= QUALITY_TOLERANCE:
+            raw = bytes.fromhex(hex_hash)
+            if len(raw) != 32:
+                raise ValueError("old-format frame hash is not 256 bits")
+            out += raw[::-1]
+    return bytes(out)
+
+
+def is_old_format(phash) -> bool:
+    """JSON text (str, or bytes starting with '[') instead of a multiple of 32 raw bytes."""
+    if isinstance(phash, str):
+        return True
+    b = bytes(phash)
+    return len(b) % 32 != 0 and b[:1] == b"["
+
+
+def upgrade_old_phashes(conn: sqlite3.Connection) -> int:
+    """In-place migration of both tables that hold perceptual hashes (db/DedupeDB.py:561-582). -> rows converted."""
+    n = 0
+    for phash_id, phash in conn.execute("SELECT phash_id, phash FROM shape_perceptual_hashes").fetchall():
+        if is_old_format(phash):
+            conn.execute("REPLACE INTO shape_perceptual_hashes ( phash_id, phash ) VALUES ( ?, ? )",
+                         (phash_id, convert_old_vpdq_to_new(phash)))
+            n += 1
+    for file_hash, phash in conn.execute("SELECT file_hash, phash FROM phashed_file_queue").fetchall():
+        if is_old_format(phash):
+            conn.execute("DELETE FROM phashed_file_queue WHERE file_hash = ?", (file_hash,))
+            conn.execute("REPLACE INTO phashed_file_queue ( file_hash, phash ) VALUES ( ?, ? )",
+                         (file_hash, convert_old_vpdq_to_new(phash)))
+            n += 1
+    conn.commit()
+    return n
+
+
+def ingest_phashed_file_queue(conn: sqlite3.Connection, tree=None) -> int:
+    """Move the hashed-but-not-inserted files into the library tables, as the reference's
+    process_phashed_file_queue does (dedup.py:396-432 with db/DedupeDB.py:241-324): file row, perceptual-hash row
+    (shared by files with an identical hash), the file's single map row, a NULL search-cache row (= still to be
+    searched), and the queue row is deleted. `tree`: a VpTreeManager facade to notify (add_leaf). -> files ingested."""
+    rows = conn.execute("SELECT file_hash, phash FROM phashed_file_queue").fetchall()
+    for file_hash, phash in rows:
+        blob = convert_old_vpdq_to_new(phash) if is_old_format(phash) else bytes(phash)
+        if len(blob) % 32:
+            raise ValueError("queued phash length is not a multiple of 32")
+        conn.execute("INSERT OR IGNORE INTO files ( file_hash ) VALUES ( ? )", (file_hash,))
+        row = conn.execute("SELECT phash_id FROM shape_perceptual_hashes WHERE phash = ?", (blob,)).fetchone()
+        if row is None:
+            conn.execute("INSERT INTO shape_perceptual_hashes ( phash ) VALUES ( ? )", (blob,))
+            row = conn.execute("SELECT phash_id FROM shape_perceptual_hashes WHERE phash = ?", (blob,)).fetchone()
+        phash_id = int(row[0])
+        hash_id = int(conn.execute("SELECT hash_id FROM files WHERE file_hash = ?", (file_hash,)).fetchone()[0])
+        if tree is not None:
+            tree.add_leaf(phash_id, blob)
+        conn.execute("DELETE FROM shape_perceptual_hash_map WHERE hash_id = ?", (hash_id,))  # one phash per file
+        conn.execute("INSERT INTO shape_perceptual_hash_map ( phash_id, hash_id ) VALUES ( ?, ? )", (phash_id, hash_id))
+        conn.execute("REPLACE INTO shape_search_cache ( hash_id, searched_distance ) VALUES ( ?, NULL )", (hash_id,))
+        conn.execute("DELETE FROM phashed_file_queue WHERE file_hash = ? AND phash = ?", (file_hash, phash))
+    conn.commit()
+    return len(rows)
 
 
 @dataclass
@@ -50,11 +127,11 @@ def load_library(conn: sqlite3.Connection) -> Library:
     ).fetchall()
     phash_ids = np.array([r[0] for r in phash_rows], dtype=np.int64)
     index_of = {int(pid): k for k, pid in enumerate(phash_ids)}
-    blobs = [bytes(r[1]) for r in phash_rows]
+    # a pre-0.10 database is read through the reference's own conversion (upgrade_old_phashes rewrites it in place)
+    blobs = [convert_old_vpdq_to_new(r[1]) if is_old_format(r[1]) else bytes(r[1]) for r in phash_rows]
     for b in blobs:
         if len(b) % 32:
-            raise ValueError("phash BLOB length is not a multiple of 32 (pre-0.10 database? run the reference's "
-                             "upgrade first, db/DedupeDB.py:434-584)")
+            raise ValueError("phash BLOB length is not a multiple of 32")
     offsets = np.zeros(len(blobs) + 1, dtype=np.int64)
     np.cumsum([len(b) // 32 for b in blobs], out=offsets[1:])
     frames = np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(-1, 32).copy()
@@ -74,7 +151,7 @@ def pending_hash_ids(conn: sqlite3.Connection, search_threshold: int) -> set:
 
 
 def find_potential_duplicates(conn: sqlite3.Connection, threshold: float = 50.0, policy: str | None = None,
-                              update_cache: bool = True, matcher=None):
+                              update_cache: bool = True, matcher=None, ingest_queue: bool = True):
     """-> (pairs, reference_count). pairs: sorted list of (file_hash_a, file_hash_b, similarity) with
     hash_id_a < hash_id_b, every unordered pair once, restricted (like the reference) to pairs with at
     least one side still to be searched. reference_count mimics the reference's return value
@@ -84,6 +161,8 @@ def find_potential_duplicates(conn: sqlite3.Connection, threshold: float = 50.0,
     matcher = search if matcher is None else matcher
     search_threshold = search.fix_vpdq_similarity(threshold)
     assert search_threshold > 0
+    if ingest_queue:  # the reference builds its tree from the queue right before searching (dedup.py:339-343)
+        ingest_phashed_file_queue(conn)
     lib = load_library(conn)
     pending = pending_hash_ids(conn, search_threshold)
     F, P = lib.hash_ids.size, lib.phash_ids.size
