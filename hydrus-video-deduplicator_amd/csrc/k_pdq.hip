@@ -64,6 +64,16 @@ __device__ __forceinline__ void grad_term(float u, float v, float& acc_m, int& a
     acc_c += (r >= 255.0f) ? 1 : 0;
 }
 
+// The same term for GRAY BYTE input in one multiply: there the operands are luma_gray(g) of a byte g, so (u, v) takes
+// only 256 x 256 values, and for every one of them trunc(|u - v| * RN(100/255)) equals the reference's
+// |(int)(((u - v) * 100) / 255)| -- checked exhaustively (tests/test_oracle.py::test_quality_term_gray_shortcut_is_exact
+// on the host, test_k1_quality_all_byte_pairs on the GPU). 4 VALU ops per term instead of 8; the quality metric was a
+// quarter of this kernel's instructions (profiles/r01_pmc_k1.txt). Float frames (the down-sampler's output) keep the
+// general form above.
+__device__ __forceinline__ void grad_term_gray(float u, float v, int& acc) {
+    acc += (int)truncf(__fmul_rn(fabsf(__fsub_rn(u, v)), 0x1.919192p-2f /* RN(100/255) = 0x3EC8C8C9 */));
+}
+
 // Lane l reads lane l+1 of the whole 64-lane wave (lane 63 reads 0 and is ignored by callers): the DPP
 // wave_shl:1 control of the GFX9 family, which folds into the consuming VALU instruction instead
 // of a trip through the LDS crossbar (ds_bpermute).
@@ -120,17 +130,28 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             }
 
             // ---- quality -----------------------------------------------------------
-            float gs = 0.0f, gh = 0.0f;
-            int cs_ = 0, ch_ = 0;
+            int gsum;
+            if (KIND == 0) {
+                int qs = 0, qh = 0;
 #pragma unroll
-            for (int k = 0; k < 63; ++k) grad_term(a[k], a[k + 1], gs, cs_);
+                for (int k = 0; k < 63; ++k) grad_term_gray(a[k], a[k + 1], qs);
 #pragma unroll
-            for (int k = 0; k < 64; ++k) grad_term(a[k], wave_next_lane(a[k]), gh, ch_);
-            if (lane < 63) {  // column 63 has no right neighbour
-                gs += gh;
-                cs_ += ch_;
+                for (int k = 0; k < 64; ++k) grad_term_gray(a[k], wave_next_lane(a[k]), qh);
+                if (lane < 63) qs += qh;  // column 63 has no right neighbour
+                gsum = (int)wave_sum_f32((float)qs);
+            } else {
+                float gs = 0.0f, gh = 0.0f;
+                int cs_ = 0, ch_ = 0;
+#pragma unroll
+                for (int k = 0; k < 63; ++k) grad_term(a[k], a[k + 1], gs, cs_);
+#pragma unroll
+                for (int k = 0; k < 64; ++k) grad_term(a[k], wave_next_lane(a[k]), gh, ch_);
+                if (lane < 63) {  // column 63 has no right neighbour
+                    gs += gh;
+                    cs_ += ch_;
+                }
+                gsum = (int)wave_sum_f32(gs + (float)cs_);
             }
-            const int gsum = (int)wave_sum_f32(gs + (float)cs_);
             int qual = gsum / 90;
             qual = qual > 100 ? 100 : qual;
 
@@ -318,17 +339,28 @@ __global__ __launch_bounds__(256, 3) void k_pdq_hash64_fma(const void* __restric
 #pragma unroll
                     for (int k = 0; k < 64; ++k) a[k] = src[k * 64];
                 }
-                float gs = 0.0f, gh = 0.0f;
-                int cs_ = 0, ch_ = 0;
+                int gsum;
+                if (KIND == 0) {  // gray bytes: the one-multiply form (grad_term_gray)
+                    int qs = 0, qh = 0;
 #pragma unroll
-                for (int k = 0; k < 63; ++k) grad_term(a[k], a[k + 1], gs, cs_);
+                    for (int k = 0; k < 63; ++k) grad_term_gray(a[k], a[k + 1], qs);
 #pragma unroll
-                for (int k = 0; k < 64; ++k) grad_term(a[k], wave_next_lane(a[k]), gh, ch_);
-                if (lane < 63) {
-                    gs += gh;
-                    cs_ += ch_;
+                    for (int k = 0; k < 64; ++k) grad_term_gray(a[k], wave_next_lane(a[k]), qh);
+                    if (lane < 63) qs += qh;
+                    gsum = (int)wave_sum_f32((float)qs);
+                } else {
+                    float gs = 0.0f, gh = 0.0f;
+                    int cs_ = 0, ch_ = 0;
+#pragma unroll
+                    for (int k = 0; k < 63; ++k) grad_term(a[k], a[k + 1], gs, cs_);
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) grad_term(a[k], wave_next_lane(a[k]), gh, ch_);
+                    if (lane < 63) {
+                        gs += gh;
+                        cs_ += ch_;
+                    }
+                    gsum = (int)wave_sum_f32(gs + (float)cs_);
                 }
-                const int gsum = (int)wave_sum_f32(gs + (float)cs_);
                 int qual = gsum / 90;
                 qual = qual > 100 ? 100 : qual;
                 if (lane == 0) quality[f] = qual;

@@ -407,3 +407,31 @@ def test_k2_auto_variant_picks_the_form_from_the_data(gpu, hvd, oracle):
     # video mode on structured frames
     off = np.arange(0, n + 1, 30, dtype=np.int64)
     assert np.array_equal(hvd.match_videos(st, off, 31), oracle.match_videos(st, off, 31))
+
+
+def test_k1_quality_all_byte_pairs(gpu, hvd, oracle):
+    """Every ordered pair of byte values as vertical AND horizontal neighbours: the gray quality metric's one-multiply
+    form (k_pdq.hip grad_term_gray) against the oracle's reference form, through the whole hash kernel, strict and fma."""
+    rng = np.random.default_rng(95)
+    pairs = np.stack(np.meshgrid(np.arange(256), np.arange(256), indexing="ij"), -1).reshape(-1, 2).astype(np.uint8)
+    rng.shuffle(pairs)
+    frames = np.zeros((32, 64, 64), dtype=np.uint8)  # 32 frames x 32 row pairs x 64 columns = 65536 vertical pairs
+    frames[:, 0::2, :] = pairs[:, 0].reshape(32, 32, 64)
+    frames[:, 1::2, :] = pairs[:, 1].reshape(32, 32, 64)
+    ext = np.zeros((4, 64, 64), dtype=np.uint8)  # saturating gradients, and differences on the 255 grid
+    ext[0, ::2] = 255
+    ext[1, :, ::2] = 255
+    ext[2] = rng.integers(0, 2, (64, 64)) * 255
+    ext[3] = 51 * rng.integers(0, 6, (64, 64))  # multiples of 51: (u - v) * 100 is a multiple of 255
+    both = np.concatenate([frames, frames.transpose(0, 2, 1), ext])  # transposed: the same pairs as horizontal neighbours
+    ho, qo = oracle.hash_frames(both, num_threads=8)
+    h, q = hvd.vpdq.hash_frames(both)
+    assert np.array_equal(q, qo) and np.array_equal(h, ho)
+    assert len(set(q.tolist())) > 1
+    hvd.vpdq.set_dct_mode("fma")
+    try:
+        hf, qf = hvd.vpdq.hash_frames(both)
+        hof, qof = oracle.hash_frames(both, num_threads=8, fma=True)
+        assert np.array_equal(qf, qo) and np.array_equal(qof, qo) and np.array_equal(hf, hof)
+    finally:
+        hvd.vpdq.set_dct_mode("strict")

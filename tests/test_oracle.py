@@ -256,3 +256,24 @@ def test_division_free_quality_term(tmp_path):
     out = subprocess.run([str(exe), stride], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert " 0 mismatches" in out.stdout
+
+
+def test_quality_term_gray_shortcut_is_exact():
+    """k_pdq_hash64 computes the quality term of GRAY BYTE frames as trunc(|u - v| * RN(100/255)) with u, v the lumas
+    of two bytes. Exhaustively over all 256 x 256 byte pairs this equals the reference's |(int)(((u - v) * 100) / 255)|
+    (pdqhashing.cpp's gradient term as the oracle restates it), all in binary32."""
+    f32 = np.float32
+    g = np.arange(256, dtype=f32)
+    y = (f32(0.299) * g).astype(f32)
+    y = (y + (f32(0.587) * g).astype(f32)).astype(f32)
+    y = (y + (f32(0.114) * g).astype(f32)).astype(f32)
+    u, v = np.meshgrid(y, y, indexing="ij")
+    d = (u - v).astype(f32)
+    ref = np.abs(np.trunc((((d * f32(100)).astype(f32)) / f32(255)).astype(f32)).astype(np.int64))
+    c = np.frombuffer(np.uint32(0x3EC8C8C9).tobytes(), dtype=f32)[0]
+    assert c == f32(100.0) / f32(255.0)
+    got = np.trunc((np.abs(d) * c).astype(f32)).astype(np.int64)
+    assert np.array_equal(got, ref) and ref.max() == 100
+    # the neighbouring floats do NOT have the property: the constant is not arbitrary
+    for other in (np.nextafter(c, f32(0)), np.nextafter(c, f32(1))):
+        assert not np.array_equal(np.trunc((np.abs(d) * other).astype(f32)).astype(np.int64), ref)
