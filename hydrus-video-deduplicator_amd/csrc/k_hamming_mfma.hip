@@ -240,28 +240,27 @@ __device__ __noinline__ void tile_hits(const v16f acc, uint32_t row0, uint32_t j
     tile_hits_body(acc, row0, j, lane, c, NEG ? -1.0f : 1.0f, NEG ? c.acc_start : 0.0f);
 }
 
-// Deferred form of the same for the kernels whose query fragments hold only the first 128 bits: `flagged` has one bit
-// per query tile of the wave whose first stage found a candidate in this 32-candidate panel. Those tiles are
+// Deferred form of the same for the kernels whose query fragments hold only the first 128 bits: `marks` has, per lane,
+// one bit per query tile of the wave whose first stage found a candidate in this 32-candidate panel. Those tiles are
 // recomputed over all 256 bits, one k-step at a time straight from memory (few registers: see load_ctx), and their
 // hits reported.
 template <int TILES>
-__device__ __noinline__ void panel_survivors(uint32_t flagged_v, const uint4* __restrict__ imgq_v, const uint4* panel_v,
+__device__ __noinline__ void panel_survivors(uint32_t marks, const uint4* __restrict__ imgq_v, const uint4* panel_v,
                                              uint32_t wrow0_v, uint32_t j0_v, uint32_t lane, const HitCtx* __restrict__ ctx) {
     // Everything but the lane id is wave-uniform; arguments of a non-kernel function arrive in VGPRs, so move them to
     // SGPRs: what stays live across the nested handler call below adds to the fast path's register footprint.
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t flagged = (uint32_t)__builtin_amdgcn_readfirstlane((int)flagged_v);
     const uint32_t wrow0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wrow0_v);
     const uint32_t j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0_v);
 #else
-    const uint32_t flagged = flagged_v, wrow0 = wrow0_v, j0 = j0_v;
+    const uint32_t wrow0 = wrow0_v, j0 = j0_v;
 #endif
     const uint4* __restrict__ imgq = (const uint4*)uniform_u64((unsigned long long)imgq_v);
     const uint4* panel = (const uint4*)uniform_u64((unsigned long long)panel_v);
     const int thr2_bits = __float_as_int(load_ctx(ctx).thr_full);
 #pragma unroll 1
     for (int t = 0; t < TILES; ++t) {
-        if (!((flagged >> t) & 1u)) continue;  // wave-uniform
+        if (!__any((marks >> (TILES - 1 - t)) & 1u)) continue;  // (per-lane marks: bit TILES-1-t <-> tile t)
         const uint32_t li = lane & 31u, h = lane >> 5;
         const uint32_t cl = (j0 & (uint32_t)(kSuper - 1)) + li;  // candidate index inside the super-panel
         const uint4* base = &panel[cl * 8u];
@@ -358,6 +357,11 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     const float hit2 = -128.5f * scale2;
     const int thr1_bits = __float_as_int(scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist));  // plain form
     const int thr2_bits = __float_as_int(scale2 * (256.0f - 2.0f * (float)max_dist));
+    // marks' = marks << 1 | verdict(acc): v_alignbit_b32 takes the sign bit of the OR straight into the mask
+    auto stage1_mark = [&](uint32_t marks, const v16f& acc) -> uint32_t {
+        if (kSign) return __builtin_amdgcn_alignbit(marks, (uint32_t)or16_bits(acc), 31);
+        return (marks << 1) | (max16_bits(acc) >= thr1_bits ? 1u : 0u);
+    };
     auto stage1_hit = [&](const v16f& acc) { return kSign ? __any(or16_bits(acc) < 0) : __any(max16_bits(acc) >= thr1_bits); };
     auto stage2_hit = [&](const v16f& acc) { return kSign ? __any(min16(acc) < hit2) : __any(max16_bits(acc) >= thr2_bits); };
 
@@ -384,18 +388,19 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
 
             // two accumulator sets: the MFMAs of tile t+1 are issued before the max tree of tile t
             if constexpr (NBR == 2) {
-                // survivors are only noted (one bit per tile, scalar) and dealt with after the panel, when no
-                // accumulator is live any more: the handler's registers add to whatever is live across its call
-                uint32_t flagged = 0;
+                // survivors are only noted -- one VALU op per tile shifts the tile's verdict (the sign of the OR, or the
+                // compare's result) into a per-lane mask -- and dealt with after the panel, when no accumulator is live
+                // any more: the handler's registers add to whatever is live across its call. One compare per PANEL.
+                uint32_t marks = 0;  // bit (TILES-1-t) <-> tile t
                 v16f cur = tile_dot<0, S1>(a[0], b, zero);
 #pragma unroll
                 for (int t = 1; t < TILES; ++t) {
                     const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
-                    flagged |= stage1_hit(cur) ? (1u << (t - 1)) : 0u;
+                    marks = stage1_mark(marks, cur);
                     cur = nxt;
                 }
-                flagged |= stage1_hit(cur) ? (1u << (TILES - 1)) : 0u;
-                if (__builtin_expect(flagged != 0u, 0)) panel_survivors<TILES>(flagged, imgq, panel, wrow0, jsp + 32u * p, lane, ctx);
+                marks = stage1_mark(marks, cur);
+                if (__builtin_expect(__any(marks != 0u), 0)) panel_survivors<TILES>(marks, imgq, panel, wrow0, jsp + 32u * p, lane, ctx);
             } else {
                 // each tile is judged on its own: a survivor's second stage runs out of registers at once, and only a
                 // tile with a real hit (all 256 bits) calls the handler

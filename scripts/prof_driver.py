@@ -8,7 +8,7 @@ import hvd_amd
 from hvd_amd import _lib as L, synth, multigpu as M
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-variant = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 13
 lib = L.init(0)
 db, _ = synth.hash_db(n, seed=3)
 d_db = L.DeviceBuffer.from_array(db)
