@@ -189,6 +189,9 @@ int hvd_init(int device) {
     }
     HIP_TRY(hipSetDevice(device));
     fill_dct(g.h_dct);
+    if (!hvd::pdq_dct_table_matches(g.h_dct))  // the hash kernel carries the matrix as instruction literals
+        return fail(HVD_ERR_STATE, "this host's libm computes a DCT matrix that differs from the table compiled into the "
+                                   "kernels (scripts/gen_dct_table.py): refusing to produce different hashes");
     hipError_t e = hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&g.ev0);
     if (e == hipSuccess) e = hipEventCreate(&g.ev1);
@@ -313,7 +316,8 @@ int hvd_get_pdq_dct_mode(void) { return hvd::g_pdq_dct_mode; }
 int hvd_debug_set(const char* key, int value) {
     if (!key) return fail(HVD_ERR_ARG, "key is NULL");
     if (strcmp(key, "pdq_dct_from_lds") == 0) {
-        hvd::g_pdq_dct_from_lds = value != 0;
+        if (value < 0 || value > 3) return fail(HVD_ERR_ARG, "pdq_dct_from_lds: 0 SGPR operands, 1 LDS, 2 literals, 3 by batch size");
+        hvd::g_pdq_dct_from_lds = value;
         return HVD_OK;
     }
     if (strcmp(key, "pdq_luma_lut") == 0) {

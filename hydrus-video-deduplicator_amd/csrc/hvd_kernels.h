@@ -70,7 +70,8 @@ hipError_t launch_match_two_small(const uint32_t* a, uint32_t na, const uint32_t
 // PDQ frame hashing. d_dct: 16*64 floats (host-computed, uploaded once).
 // kind 0: gray u8 64x64 frames; kind 1: float 64x64 buffers (output of the
 // down-sampler). d_in strides are implied by kind.
-extern bool g_pdq_dct_from_lds;
+extern int g_pdq_dct_from_lds;
+bool pdq_dct_table_matches(const float* host_16x64);  // the kernels' compile-time DCT table vs the host's computation
 extern int g_pdq_luma_lut;
 extern int g_pdq_dct_mode;
 extern bool g_pdq_fused_down512;

@@ -23,6 +23,7 @@
 //   bits     ballot(B > median): lane l, output r is hash bit l + 64 r
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "hvd_kernels.h"
 
@@ -88,10 +89,20 @@ __device__ __forceinline__ float wave_sum_f32(float v) {  // exact: integer-valu
     return v;
 }
 
+// The DCT matrix as compile-time constants (scripts/gen_dct_table.py; hvd_init refuses to start if the host's own
+// computation of the matrix differs from this table).
+constexpr uint32_t kDctBits[16][64] = {
+#include "dct_table.inc"
+};
+__device__ __forceinline__ constexpr float dct_lit(int i, int k) { return __builtin_bit_cast(float, kDctBits[i][k]); }
+
 // KIND 0: uint8 gray 64x64 frames. KIND 1: float 64x64 buffers (down-sampler output).
-// DLDS: stage 1 takes D[i][k] from LDS broadcast reads (VGPR operands, full-rate v_mul) instead of
-// scalar loads (SGPR operands: v_mul_f32 s,v issues at half rate, profiles/r01_ubench_valu.txt).
-template <int KIND, bool DLDS, int LUT>
+// DLDS: where stage 1 takes D[i][k] from. 0: scalar loads (SGPR operands: v_mul_f32 s,v issues at half rate,
+// profiles/r01_ubench_valu.txt). 1: LDS broadcast reads (VGPR operands, full-rate v_mul, but an LDS read per 4
+// products). 2: 32-bit LITERALS in the instruction stream -- the matrix is a constant of the algorithm, so stage 1 is
+// unrolled completely (16 x 64 multiply-adds, ~20 KB of code) and every multiply carries its coefficient: no operand
+// fetch at all, full-rate issue.
+template <int KIND, int DLDS, int LUT>
 __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in, long long n,
                                                     const float* __restrict__ dct, uint8_t* __restrict__ hashes,
                                                     int32_t* __restrict__ quality) {
@@ -156,10 +167,27 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             qual = qual > 100 ? 100 : qual;
 
             // ---- stage 1: T[i][lane] = sum_k D[i][k] * a[k], k ascending ------------
+            if (DLDS == 2) {
+#pragma unroll
+                for (int i0 = 0; i0 < 16; i0 += 4) {
+                    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) {
+                        s0 = __fadd_rn(s0, __fmul_rn(dct_lit(i0 + 0, k), a[k]));
+                        s1 = __fadd_rn(s1, __fmul_rn(dct_lit(i0 + 1, k), a[k]));
+                        s2 = __fadd_rn(s2, __fmul_rn(dct_lit(i0 + 2, k), a[k]));
+                        s3 = __fadd_rn(s3, __fmul_rn(dct_lit(i0 + 3, k), a[k]));
+                    }
+                    lds.T[wave][i0 + 0][lane] = s0;
+                    lds.T[wave][i0 + 1][lane] = s1;
+                    lds.T[wave][i0 + 2][lane] = s2;
+                    lds.T[wave][i0 + 3][lane] = s3;
+                }
+            } else
 #pragma unroll 1
             for (int i0 = 0; i0 < 16; i0 += 4) {
                 float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-                if (DLDS) {
+                if (DLDS == 1) {
 #pragma unroll
                     for (int k4 = 0; k4 < 16; ++k4) {  // same address in every lane: LDS broadcast
                         const float4 e0 = *reinterpret_cast<const float4*>(&lds.D[i0 + 0][4 * k4]);
@@ -1234,7 +1262,20 @@ namespace hvd {
 
 int g_pdq_dct_mode = 0;           // 0: strict mul-then-add on the VALU (default); 1: fma chain on the matrix cores
 int g_pdq_luma_lut = 1;           // 0: compute luma, 1: LDS table, 2: LDS table, loads in groups of 16
-bool g_pdq_dct_from_lds = false;  // A/B switch (hvd_debug_set): stage-1 DCT operand from LDS vs SGPR; measured equal
+// stage-1 DCT operand source (hvd_debug_set "pdq_dct_from_lds"): 0 SGPRs, 1 LDS, 2 literals, 3 (default) by batch size --
+// literals from 64k frames on (+9 % at 400k frames: full-rate multiplies), SGPRs below (the unrolled 21 KB of code cost
+// 4 % at 10k frames, where every workgroup runs it once or twice; profiles/r02_k1_dct_operand.txt)
+int g_pdq_dct_from_lds = 3;
+
+bool pdq_dct_table_matches(const float* host_16x64) {
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 64; ++k) {
+            uint32_t w;
+            memcpy(&w, &host_16x64[i * 64 + k], 4);
+            if (w != kDctBits[i][k]) return false;
+        }
+    return true;
+}
 
 hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
                              int32_t* d_quality, hipStream_t s) {
@@ -1249,16 +1290,19 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
             hipLaunchKernelGGL(k_pdq_hash64_fma<1>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
         return hipGetLastError();
     }
-    const bool dlds = g_pdq_dct_from_lds;
+    const int dlds = g_pdq_dct_from_lds == 3 ? (n >= 65536 ? 2 : 0) : g_pdq_dct_from_lds;
     const int lut = g_pdq_luma_lut;
 #define HVD_K1(KIND, D, L) hipLaunchKernelGGL((k_pdq_hash64<KIND, D, L>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality)
     if (kind == 0) {
-        if (dlds) HVD_K1(0, true, 1);
-        else if (lut == 0) HVD_K1(0, false, 0);
-        else if (lut == 1) HVD_K1(0, false, 1);
-        else HVD_K1(0, false, 2);
+        if (dlds == 2) HVD_K1(0, 2, 1);
+        else if (dlds == 1) HVD_K1(0, 1, 1);
+        else if (lut == 0) HVD_K1(0, 0, 0);
+        else if (lut == 1) HVD_K1(0, 0, 1);
+        else HVD_K1(0, 0, 2);
     } else {
-        if (dlds) HVD_K1(1, true, 0); else HVD_K1(1, false, 0);
+        if (dlds == 2) HVD_K1(1, 2, 0);
+        else if (dlds == 1) HVD_K1(1, 1, 0);
+        else HVD_K1(1, 0, 0);
     }
 #undef HVD_K1
     return hipGetLastError();

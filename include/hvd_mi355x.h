@@ -159,7 +159,7 @@ int hvd_set_pdq_dct_mode(int mode);
 int hvd_get_pdq_dct_mode(void);
 
 /* Developer switches for A/B measurements; results never change, only which kernel form runs:
- *   "pdq_dct_from_lds" 0|1, "pdq_luma_lut" 0|1|2           (64x64 hash kernel)
+ *   "pdq_dct_from_lds" 0|1|2|3 (SGPR | LDS | literals | by batch size), "pdq_luma_lut" 0|1|2   (64x64 hash kernel)
  *   "pdq_fused_down512" 0|1                                (0: generic 4-launch down-sampler)
  *   "pdq_down512_wave" 0|1|2                               (wave-per-frame kernel: never | batches >= 704 | always)
  *   "pdq_down512_wave_grid" n                              (waves in flight; 0 = what is resident at once)

@@ -11,3 +11,18 @@ find $OUT/r02_stats -name "*kernel_stats.csv" | head -3
 cd $REPO && bash scripts/profile_pmc.sh r02
 python scripts/pmc_summary.py gpurun_out/pmc_r02 > gpurun_out/r02_pmc_summary.txt 2>&1
 tail -5 gpurun_out/r02_pmc_summary.txt
+# 3. traffic + SQ counters of the two frame-hash kernels (64x64 gray at 10k and 400k frames; 512x512 rgb at 6144)
+cd $REPO
+for N in 10000 400000; do
+  O2=$OUT/pmc_r02_k1_$N; mkdir -p $O2
+  ( cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O2/stats -o stats -- python $REPO/scripts/prof_k1.py $N > $O2/stats.log 2>&1
+    for grp in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" "sq2 SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+      set -- $grp; name=$1; shift
+      rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O2/$name -o $name -- python $REPO/scripts/prof_k1.py $N > $O2/$name.log 2>&1
+    done )
+  python scripts/pmc_summary.py $O2 > $OUT/r02_pmc_k1_$N.txt 2>&1
+done
+bash scripts/profile_rgb.sh r02_rgb 1 stats sq1 sq2 fetch wr tcc > /dev/null 2>&1
+python scripts/pmc_summary.py gpurun_out/pmc_r02_rgb > gpurun_out/r02_pmc_down512w.txt 2>&1
+echo "profile set done"

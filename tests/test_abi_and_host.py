@@ -184,3 +184,19 @@ def test_similarity_of_records_direction_rules(hvd):
 def test_find_potential_duplicates_rejects_bad_blobs_before_touching_the_gpu(hvd):
     with pytest.raises(ValueError):
         hvd.find_potential_duplicates([b"\0" * 32, b"\0" * 31])
+
+
+def test_compiled_dct_table_is_the_host_matrix(hvd, oracle):
+    """The 64x64 hash kernel carries the DCT matrix as instruction literals (csrc/dct_table.inc, generated by
+    scripts/gen_dct_table.py); it must be bit-identical to what the library's host code and the oracle compute."""
+    import ctypes as C
+
+    from hvd_amd import _lib
+
+    txt = open(os.path.join(ROOT, "hydrus-video-deduplicator_amd", "csrc", "dct_table.inc")).read()
+    baked = np.array([int(x, 16) for x in re.findall(r"0x([0-9A-F]{8})u", txt)], dtype=np.uint32)
+    assert baked.size == 16 * 64
+    host = np.zeros(16 * 64, dtype=np.float32)
+    _lib.check(_lib.load().hvd_dct_matrix(host.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(host.view(np.uint32), baked)
+    assert np.array_equal(oracle.dct_matrix().reshape(-1).view(np.uint32), baked)

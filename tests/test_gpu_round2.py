@@ -410,24 +410,31 @@ def test_k2_auto_variant_picks_the_form_from_the_data(gpu, hvd, oracle):
 
 
 def test_k1_quality_all_byte_pairs(gpu, hvd, oracle):
-    """Every ordered pair of byte values as vertical AND horizontal neighbours: the gray quality metric's one-multiply
-    form (k_pdq.hip grad_term_gray) against the oracle's reference form, through the whole hash kernel, strict and fma."""
+    """The gray quality metric's one-multiply form (k_pdq.hip grad_term_gray) through the whole hash kernel, strict and
+    fma, against the oracle's reference form. (a) Every ordered pair of byte values as vertical and as horizontal
+    neighbours (these frames saturate the metric at 100: a smoke test of the clamp); (b) UNSATURATED frames: a constant A
+    with 45 isolated pixels B -- 180 neighbour pairs, so quality = 2 * term(A, B) exactly -- for 3000 random (A, B) and
+    for every pair whose difference is a multiple of 51, where (u - v) * 100 lands on a multiple of 255 and the luma
+    rounding errors decide the truncation."""
     rng = np.random.default_rng(95)
     pairs = np.stack(np.meshgrid(np.arange(256), np.arange(256), indexing="ij"), -1).reshape(-1, 2).astype(np.uint8)
     rng.shuffle(pairs)
     frames = np.zeros((32, 64, 64), dtype=np.uint8)  # 32 frames x 32 row pairs x 64 columns = 65536 vertical pairs
     frames[:, 0::2, :] = pairs[:, 0].reshape(32, 32, 64)
     frames[:, 1::2, :] = pairs[:, 1].reshape(32, 32, 64)
-    ext = np.zeros((4, 64, 64), dtype=np.uint8)  # saturating gradients, and differences on the 255 grid
-    ext[0, ::2] = 255
-    ext[1, :, ::2] = 255
-    ext[2] = rng.integers(0, 2, (64, 64)) * 255
-    ext[3] = 51 * rng.integers(0, 6, (64, 64))  # multiples of 51: (u - v) * 100 is a multiple of 255
-    both = np.concatenate([frames, frames.transpose(0, 2, 1), ext])  # transposed: the same pairs as horizontal neighbours
+    ab = [(a, b) for a in range(256) for b in range(256) if a != b and abs(a - b) % 51 == 0]
+    ab += [tuple(x) for x in rng.integers(0, 256, (3000, 2))]
+    ab = np.array(ab, dtype=np.uint8)
+    iso = np.repeat(ab[:, 0], 4096).reshape(-1, 64, 64).copy()
+    ys, xs = np.meshgrid(np.arange(2, 62, 4), np.arange(2, 62, 4), indexing="ij")  # 15 x 15 interior sites, 4 apart
+    sites = np.stack([ys.ravel(), xs.ravel()], 1)[:45]
+    iso[:, sites[:, 0], sites[:, 1]] = ab[:, 1:2]
+    both = np.concatenate([frames, frames.transpose(0, 2, 1), iso])  # transposed: the same pairs as horizontal neighbours
     ho, qo = oracle.hash_frames(both, num_threads=8)
     h, q = hvd.vpdq.hash_frames(both)
     assert np.array_equal(q, qo) and np.array_equal(h, ho)
-    assert len(set(q.tolist())) > 1
+    qi = q[64:]
+    assert len(set(qi.tolist())) > 40 and qi.max() == 100 and (qi % 2 == 0).all()  # unsaturated: 2 * term
     hvd.vpdq.set_dct_mode("fma")
     try:
         hf, qf = hvd.vpdq.hash_frames(both)
