@@ -220,6 +220,11 @@ def main():
 
     total_cmp = n * (n - 1) // 2
     head = allpairs_workload(n, seed, args.steps, args.warmup)
+    form = variant
+    if variant == 13:  # which of its two forms did the probe choose for this DB? (read before any other leg launches)
+        fv = C.c_int(0)
+        L.check(lib.hvd_debug_get(b"mfma_auto_form", C.byref(fv)))
+        form = fv.value
     d_db, d_img, d_pairs, d_cnt = head["bufs"]
     db = head["db"]
     elapsed, merged = head["elapsed"], head["merged"]
@@ -339,11 +344,6 @@ def main():
                  "frac": round(achieved / HBM_PEAK_GBS, 3),
                  "note": "SURVEY.md 8d accounting: 64 B per comparison with no operand reuse credited; frac > 1 "
                          "because tiles re-use operands from registers/LDS"}
-    form = variant
-    if variant == 13:  # which of its two forms did the probe choose for this DB?
-        fv = C.c_int(0)
-        L.check(lib.hvd_debug_get(b"mfma_auto_form", C.byref(fv)))
-        form = fv.value
     if variant >= 8:
         # executed matrix work: 2 (128-bit first stage) or 4 MFMAs of 2*32*32*64 flop per 1024 comparisons
         flop_per_cmp = 256.0 if form in (9, 11, 12) else 512.0
@@ -404,7 +404,7 @@ def main():
         dq2.free()
         m400, s400 = mean_sd(kl)
         frames_out["batch_400k"] = {"value": sig(400_000 / (m400 * 1e-3)), "unit": "frames/s", "kernel_ms": round(m400, 3),
-                                    "kernel_ms_sd": round(s400, 3),
+                                    "kernel_ms_sd": round(s400, 3), "traffic": load_traffic("pdq_hash64_n400000"),
                                     "hbm_frac": round(400_000 / (m400 * 1e-3) * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4)}
 
         # the headline DB again for the side-by-side legs
