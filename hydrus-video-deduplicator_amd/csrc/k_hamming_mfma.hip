@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "hvd_devhash.h"
 #include "hvd_kernels.h"
 
@@ -626,7 +628,9 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
 // select[0] = form to run, select[1] = survivors counted by the probe, select[2..3] spare. One per process (all
 // launches go to the one library stream).
 static uint32_t* g_select = nullptr;
-uint32_t g_mfma_auto_last[2] = {0, 0};  // for tests: not read back unless asked (hvd_debug_get)
+// The hit context and the select words are shared device state written in stream order right before the kernels that
+// read them: two host threads enqueueing passes at once must not interleave "write context, launch" sequences.
+static std::mutex g_launch_mu;
 
 hipError_t mfma_select_buffer(uint32_t** out) {
     if (!g_select) {
@@ -675,6 +679,7 @@ static int effective_variant(int variant, uint32_t max_dist) {
 hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
                              const int32_t* d_group_t, hipStream_t s) {
     if (nq == 0 || a.n == 0) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_launch_mu);
     if (a.max_dist >= 128u) return hipErrorInvalidValue;  // sign trick needs a positive threshold
     const int v = effective_variant(a.variant, a.max_dist);
     if (v == 13) return launch_auto(a, d_img_t, true, d_img_q, nq, d_group_t, s);
@@ -693,6 +698,7 @@ hipError_t launch_allpairs_mfma(const AllPairsArgs& a_in, const void* d_img, hip
         return launch_allpairs(a, s);
     }
     const int v = effective_variant(a.variant, a.max_dist);
+    std::lock_guard<std::mutex> lk(g_launch_mu);
     if (v == 13) return launch_auto(a, d_img, false, nullptr, 0u, nullptr, s);
     return launch_variant(v, a, d_img, false, nullptr, 0u, nullptr, nullptr, s);
 }

@@ -442,3 +442,38 @@ def test_k1_quality_all_byte_pairs(gpu, hvd, oracle):
         assert np.array_equal(qf, qo) and np.array_equal(qof, qo) and np.array_equal(hf, hof)
     finally:
         hvd.vpdq.set_dct_mode("strict")
+
+
+def test_k2_device_api_from_two_threads(gpu, hvd, oracle):
+    """The all-pairs launch writes a launch-uniform context into device memory right before the kernel that reads it;
+    two host threads enqueueing passes concurrently (GUI worker + main thread) must each get their own pairs."""
+    import threading
+
+    dbs = [hvd.synth.hash_db(6000 + 500 * k, seed=96 + k, plant_fraction=0.02)[0] for k in range(2)]
+    want = [oracle.allpairs(db, 31, num_threads=4) for db in dbs]
+    out, errs = [None, None], []
+
+    def work(k):
+        try:
+            lib = gpu.load()
+            d_db = gpu.DeviceBuffer.from_array(dbs[k])
+            d_img = hvd.multigpu.expand_fp4(d_db.ptr, len(dbs[k]))
+            d_pairs, d_cnt = gpu.DeviceBuffer(16 * 4096), gpu.DeviceBuffer(8)
+            for _ in range(30):
+                d_cnt.zero()
+                hvd.multigpu.launch_allpairs(lib, d_db.ptr, d_img.ptr, len(dbs[k]), None, 31, 0, 1, d_pairs.ptr, 4096,
+                                             d_cnt.ptr, 13 if k == 0 else 9)
+                cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+                got = hvd.multigpu.merge_pairs([d_pairs.to_array(gpu.PAIR_DTYPE, cnt)])
+                if not np.array_equal(got, want[k]):
+                    raise AssertionError(f"thread {k}: wrong pair list")
+            out[k] = True
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs and out == [True, True], errs
