@@ -175,6 +175,43 @@ class DeviceLibrary:
         self.d_img = None
 
 
+def shard_frames(raw_offsets: np.ndarray, world: int) -> int:
+    """Frames in the longest rank's share (shards are padded to it for the equal-size all-gather)."""
+    V = raw_offsets.size - 1
+    return max(int(raw_offsets[video_range_of_rank(V, r, world)[1]] - raw_offsets[video_range_of_rank(V, r, world)[0]])
+               for r in range(world))
+
+
+def gather_hash_shards(d_h: DeviceBuffer, d_q: DeviceBuffer, raw_offsets: np.ndarray, rank: int, world: int, exchange):
+    """All-gather of the per-rank hash / quality shards (RCCL, equal-size padded blocks), then the padding is
+    squeezed out so that the frames are in library order. -> (d_hashes, d_quality) for the whole library."""
+    lib = _lib.ensure()
+    V = raw_offsets.size - 1
+    n_total = int(raw_offsets[-1])
+    v_lo, v_hi = video_range_of_rank(V, rank, world)
+    n_mine = int(raw_offsets[v_hi] - raw_offsets[v_lo])
+    shard = max(1, shard_frames(raw_offsets, world))
+    d_all_h, d_all_q = DeviceBuffer(32 * shard * world), DeviceBuffer(4 * shard * world)
+    d_ph, d_pq = DeviceBuffer(32 * shard), DeviceBuffer(4 * shard)  # my shard, padded to the longest
+    d_ph.zero()
+    d_pq.zero()
+    _lib.check(lib.hvd_memcpy_d2d(d_ph.ptr, d_h.ptr, 32 * n_mine))
+    _lib.check(lib.hvd_memcpy_d2d(d_pq.ptr, d_q.ptr, 4 * n_mine))
+    exchange.allgather_bytes_dev(d_ph.ptr, d_all_h.ptr, 32 * shard)
+    exchange.allgather_bytes_dev(d_pq.ptr, d_all_q.ptr, 4 * shard)
+    d_fh, d_fq = DeviceBuffer(32 * max(n_total, 1)), DeviceBuffer(4 * max(n_total, 1))
+    for r in range(world):  # ranks own contiguous video ranges
+        lo, hi = video_range_of_rank(V, r, world)
+        a, b = int(raw_offsets[lo]), int(raw_offsets[hi])
+        if b > a:
+            _lib.check(lib.hvd_memcpy_d2d(d_fh.ptr + 32 * a, d_all_h.ptr + 32 * shard * r, 32 * (b - a)))
+            _lib.check(lib.hvd_memcpy_d2d(d_fq.ptr + 4 * a, d_all_q.ptr + 4 * shard * r, 4 * (b - a)))
+    _lib.check(lib.hvd_dev_sync())  # the staging buffers are freed below
+    for buf in (d_all_h, d_all_q, d_ph, d_pq):
+        buf.free()
+    return d_fh, d_fq
+
+
 def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, w: int, channels: int,
                             threshold: float = 50.0, policy: str | None = None, rank: int = 0, world: int = 1,
                             exchange=None, keep_library: bool = False):
@@ -183,37 +220,18 @@ def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, 
     shards) -> quality filter + CSR -> FP4 image -> sharded video search with the counters reduced on the GPU
     -> pair predicate of dedup.py:445-502 on the few video-level records.
     -> (pairs int64[m,2], records, library or None). Every rank returns the same result."""
-    lib = _lib.ensure()
     raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.int64)
     V = raw_offsets.size - 1
     n_total = int(raw_offsets[-1])
     v_lo, v_hi = video_range_of_rank(V, rank, world)
-    f_lo, f_hi = int(raw_offsets[v_lo]), int(raw_offsets[v_hi])
-    n_mine = f_hi - f_lo
+    n_mine = int(raw_offsets[v_hi] - raw_offsets[v_lo])
     d_h, d_q = hash_frames_on_device(d_frames_ptr, n_mine, h, w, channels)
     if world > 1:
         if exchange is None:
             raise ValueError("world > 1 needs the RCCL exchange")
-        shard = max(int(raw_offsets[video_range_of_rank(V, r, world)[1]] - raw_offsets[video_range_of_rank(V, r, world)[0]])
-                    for r in range(world))
-        d_all_h, d_all_q = DeviceBuffer(32 * shard * world), DeviceBuffer(4 * shard * world)
-        d_ph, d_pq = DeviceBuffer(32 * shard), DeviceBuffer(4 * shard)  # my shard, padded to the longest
-        d_ph.zero()
-        d_pq.zero()
-        _lib.check(lib.hvd_memcpy_d2d(d_ph.ptr, d_h.ptr, 32 * n_mine))
-        _lib.check(lib.hvd_memcpy_d2d(d_pq.ptr, d_q.ptr, 4 * n_mine))
-        exchange.allgather_bytes_dev(d_ph.ptr, d_all_h.ptr, 32 * shard)
-        exchange.allgather_bytes_dev(d_pq.ptr, d_all_q.ptr, 4 * shard)
-        # ranks own contiguous video ranges: squeeze the padding out so that the frames are in library order
-        d_fh, d_fq = DeviceBuffer(32 * max(n_total, 1)), DeviceBuffer(4 * max(n_total, 1))
-        for r in range(world):
-            lo, hi = video_range_of_rank(V, r, world)
-            a, b = int(raw_offsets[lo]), int(raw_offsets[hi])
-            if b > a:
-                _lib.check(lib.hvd_memcpy_d2d(d_fh.ptr + 32 * a, d_all_h.ptr + 32 * shard * r, 32 * (b - a)))
-                _lib.check(lib.hvd_memcpy_d2d(d_fq.ptr + 4 * a, d_all_q.ptr + 4 * shard * r, 4 * (b - a)))
-        for buf in (d_h, d_q, d_all_h, d_all_q, d_ph, d_pq):
-            buf.free()
+        d_fh, d_fq = gather_hash_shards(d_h, d_q, raw_offsets, rank, world, exchange)
+        d_h.free()
+        d_q.free()
         d_h, d_q = d_fh, d_fq
     library = DeviceLibrary.from_raw_hashes(d_h.ptr, d_q.ptr, n_total, raw_offsets)
     d_h.free()

@@ -477,3 +477,83 @@ def test_k2_device_api_from_two_threads(gpu, hvd, oracle):
     for t in ts:
         t.join()
     assert not errs and out == [True, True], errs
+
+
+class _LoopbackAllGather:
+    """All ranks of a sharded run simulated one after the other on this GPU: sweep 1 registers every rank's send
+    buffers, sweep 2 serves the all-gathers from them (test-side stand-in for hvd_comm_allgather_bytes)."""
+
+    def __init__(self, gpu, world):
+        self.gpu, self.world = gpu, world
+        self.sent = {}   # (call index, rank) -> DeviceBuffer copy of the send buffer
+        self.rank, self.call, self.record = 0, 0, True
+
+    def start(self, rank, record):
+        self.rank, self.call, self.record = rank, 0, record
+
+    def allgather_bytes_dev(self, d_send_ptr, d_recv_ptr, nbytes):
+        lib = self.gpu.load()
+        if self.record:
+            keep = self.gpu.DeviceBuffer(nbytes)
+            self.gpu.check(lib.hvd_memcpy_d2d(keep.ptr, d_send_ptr, nbytes))
+            self.sent[(self.call, self.rank)] = keep
+        else:
+            for r in range(self.world):
+                self.gpu.check(lib.hvd_memcpy_d2d(d_recv_ptr + r * nbytes, self.sent[(self.call, r)].ptr, nbytes))
+        self.gpu.check(lib.hvd_dev_sync())
+        self.call += 1
+
+
+@pytest.mark.parametrize("world,V", [(2, 301), (3, 100), (8, 50), (8, 5)])
+def test_config5_rank_sharding_simulated(gpu, hvd, oracle, world, V):
+    """The multi-rank config-5 path (disjoint video ranges hashed per rank, padded shards all-gathered, padding squeezed
+    out, whole library compacted on every rank, tiles searched per rank) with the ranks run one after the other on this
+    GPU and a loopback all-gather: every rank must assemble the single-GPU library, and the ranks' partial searches must
+    cover the single-GPU records (key exchange off: max <= truth <= sum per counter). V = 5 < world: ranks with no video."""
+    F = 6
+    lib = gpu.load()
+    copy_of = np.full(V, -1, dtype=np.int32)
+    if V > 10:
+        copy_of[V // 2] = 1
+        copy_of[V - 1] = 3
+    d_copy = gpu.DeviceBuffer.from_array(copy_of)
+    raw_off = np.arange(V + 1, dtype=np.int64) * F
+    d_all = gpu.DeviceBuffer(V * F * 4096)
+    gpu.check(lib.hvd_dev_synth_video_frames(d_all.ptr, 0, V, F, 7, d_copy.ptr))
+    _, want_recs, want_lib = hvd.pipeline.dedupe_frames_on_device(d_all.ptr, raw_off, 64, 64, 1, keep_library=True)
+    want_hashes, want_off = want_lib.hashes(), want_lib.offsets()
+    want_lib.free()
+    loop = _LoopbackAllGather(gpu, world)
+    shards = {}
+    for sweep in (0, 1):
+        for r in range(world):
+            loop.start(r, record=(sweep == 0))
+            lo, hi = hvd.pipeline.video_range_of_rank(V, r, world)
+            d_fr = gpu.DeviceBuffer(max(1, (hi - lo) * F * 4096))  # this rank generates only its own videos
+            gpu.check(lib.hvd_dev_synth_video_frames(d_fr.ptr, lo, hi - lo, F, 7, d_copy.ptr))
+            d_h, d_q = hvd.pipeline.hash_frames_on_device(d_fr.ptr, (hi - lo) * F, 64, 64, 1)
+            d_fh, d_fq = hvd.pipeline.gather_hash_shards(d_h, d_q, raw_off, r, world, loop)
+            if sweep == 1:
+                library = hvd.pipeline.DeviceLibrary.from_raw_hashes(d_fh.ptr, d_fq.ptr, V * F, raw_off)
+                assert np.array_equal(library.hashes(), want_hashes) and np.array_equal(library.offsets(), want_off)
+                gpu.check(lib.hvd_debug_set(b"vmatch_exchange", 2))
+                try:
+                    shards[r] = library.match_videos(rank=r, world=world)
+                finally:
+                    gpu.check(lib.hvd_debug_set(b"vmatch_exchange", 0))
+                library.free()
+            for b in (d_fr, d_h, d_q, d_fh, d_fq):
+                b.free()
+    want = {(int(x["a"]), int(x["b"])): (int(x["q_hits"]), int(x["t_hits"])) for x in want_recs}
+    mx, sm = {}, {}
+    for part in shards.values():
+        for x in part:
+            k = (int(x["a"]), int(x["b"]))
+            q, t = int(x["q_hits"]), int(x["t_hits"])
+            mx[k] = (max(mx.get(k, (0, 0))[0], q), max(mx.get(k, (0, 0))[1], t))
+            sm[k] = (sm.get(k, (0, 0))[0] + q, sm.get(k, (0, 0))[1] + t)
+    assert set(mx) == set(want)
+    for k, (q, t) in want.items():
+        assert mx[k][0] <= q <= sm[k][0] and mx[k][1] <= t <= sm[k][1]
+    if V > 10:
+        assert (1, V // 2) in want and (3, V - 1) in want
