@@ -364,13 +364,14 @@ int hvd_debug_set(const char* key, int value) {
 int hvd_debug_get(const char* key, int* out_value) {
     if (int rc = need_ready()) return rc;
     if (!key || !out_value) return fail(HVD_ERR_ARG, "NULL argument");
-    if (strcmp(key, "mfma_auto_form") == 0 || strcmp(key, "mfma_probe_survivors") == 0) {
+    const bool want_form = strcmp(key, "mfma_auto_form") == 0;
+    if (want_form || strcmp(key, "mfma_probe_survivors") == 0) {
         uint32_t* sel = nullptr;
         HIP_TRY(hvd::mfma_select_buffer(&sel));
         uint32_t v[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(v, sel, 8, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        *out_value = (int)v[key[5] == 'a' ? 0 : 1];
+        *out_value = (int)v[want_form ? 0 : 1];
         return HVD_OK;
     }
     return fail(HVD_ERR_ARG, "unknown debug key %s", key);

@@ -156,22 +156,23 @@ class VpTreeManager:
         return list(best.items())
 
     def search_perceptual_hashes(self, search_perceptual_hashes, max_hamming_distance: int) -> list:
-        """db/vptree.py:664-815 for hashes that are in the library (what search_file passes)."""
+        """db/vptree.py:664-815: library hashes (what search_file passes) are answered from the cached pass, any other
+        hash by one rectangular pass against the library."""
         out = []
         if len(search_perceptual_hashes) == 0:
             return out
         self._load()
-        found = []
+        found, foreign = [], []
         for blob in search_perceptual_hashes:
+            blob = bytes(blob)
             row = self.db.execute("SELECT phash_id FROM shape_perceptual_hashes WHERE phash = :phash;",
                                   {"phash": blob}).fetchone()
             if row is None:
-                if max_hamming_distance == 0:
-                    continue
-                raise KeyError("search_perceptual_hashes: the hash is not in shape_perceptual_hashes; add it with add_leaf first")
+                foreign.append(blob)  # not a library hash: compared against the library on the fly below
+                continue
             pid = int(row[0])
             if pid not in self._index:
-                self._append(pid, bytes(blob))
+                self._append(pid, blob)
             found.append(self._index[pid])
         if max_hamming_distance == 0:  # identical perceptual hashes only
             return dedupe_list(self._files_of([(p, 0) for p in found]))
@@ -179,6 +180,21 @@ class VpTreeManager:
         hits = []
         for p in found:
             hits.extend(self._similar_positions(p, max_hamming_distance))
+        foreign = [b for b in foreign if len(b)]
+        if foreign and self._blobs:  # one rectangular pass: the foreign hashes as queries against the whole library
+            if any(len(b) % vpdq.BYTES_PER_PDQ_HASH for b in foreign):
+                raise ValueError("phash BLOB length is not a multiple of 32")
+            lens = np.array([len(b) // 32 for b in foreign], dtype=np.int64)
+            oq = np.zeros(lens.size + 1, dtype=np.int64)
+            np.cumsum(lens, out=oq[1:])
+            fq = np.frombuffer(b"".join(foreign), dtype=np.uint8).reshape(-1, 32)
+            ft, ot, lt = self._csr(0, len(self._blobs))
+            recs = self._matcher.match_videos_cross(fq, oq, ft, ot, max_dist=vpdq.frame_max_dist(search.DISTANCE_TOLERANCE))
+            for r in recs:
+                d = fix_vpdq_similarity(vpdq.percent_from_hits(int(r["q_hits"]), int(r["t_hits"]), int(lens[int(r["a"])]),
+                                                               int(lt[int(r["b"])])))
+                if d <= max_hamming_distance:
+                    hits.append((int(r["b"]), d))
         return dedupe_list(self._files_of(hits))
 
     def search_file(self, hash_id: int, max_hamming_distance: int) -> list:

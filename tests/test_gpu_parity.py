@@ -2,6 +2,7 @@
 C-ABI, against the CPU oracle on the same seeded inputs and against the committed golden
 fixtures. Bit-exact: hashes, qualities, pair lists and match counters are integers/bytes."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -596,7 +597,7 @@ def test_k1_down512_large_batch_takes_the_wave_kernel(gpu, hvd, oracle):
     assert np.array_equal(h, np.concatenate([ho] * 16)) and np.array_equal(q, np.concatenate([qo] * 16))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HVD_SWEEP_SEEDS", "12"))))
 def test_randomized_differential_sweep(gpu, hvd, oracle, seed):
     """Seeded random shapes around the padding / tile / super-panel boundaries (127, 128, 1023,
     1024, 1025, 2047 ...), random tolerances, group maps, rank splits and query x target shapes:
@@ -613,7 +614,7 @@ def test_randomized_differential_sweep(gpu, hvd, oracle, seed):
     # host entry (default kernel)
     assert np.array_equal(hvd.allpairs_hamming(db, md, group=grp), want)
     # every device variant
-    for variant in (0, 1, 3, 8, 9, 10, 11):
+    for variant in (0, 1, 3, 8, 9, 10, 11, 12, 13):
         assert np.array_equal(_run_variant(gpu, hvd, db, variant, max_dist=md, group=grp, cap=max(len(want), 16)), want), variant
     # rank split of the default kernel
     world = int(rng.integers(2, 6))
@@ -626,7 +627,13 @@ def test_randomized_differential_sweep(gpu, hvd, oracle, seed):
     V = int(rng.integers(2, 120))
     frames, offsets, _ = hvd.synth.video_hashes(V, seed=3000 + seed, frames_per_video=(0, int(rng.integers(1, 40))),
                                                 copy_fraction=0.3)
-    assert np.array_equal(hvd.match_videos(frames, offsets, 31), oracle.match_videos(frames, offsets, 31))
+    want_v = oracle.match_videos(frames, offsets, 31)
+    assert np.array_equal(hvd.match_videos(frames, offsets, 31), want_v)
+    dl = hvd.pipeline.DeviceLibrary.from_host(frames, offsets)  # device-resident form, tiny record buffer (re-emit)
+    try:
+        assert np.array_equal(dl.match_videos(31, cap=int(rng.integers(1, 50))), want_v)
+    finally:
+        dl.free()
     q_sel = rng.choice(V, size=int(rng.integers(1, V + 1)), replace=False)
     blobs = [frames[offsets[p]:offsets[p + 1]] for p in q_sel]
     fq = np.concatenate(blobs) if sum(len(b) for b in blobs) else np.zeros((0, 32), np.uint8)

@@ -74,6 +74,14 @@ def check_facade(hvd, oracle, matcher):
     tree2 = hvd.vptree.VpTreeManager(conn, matcher=matcher)
     for hash_id in (1, 4, 21, n + 1, n + 2):
         assert sorted(tree2.search_file(hash_id, 51)) == sorted(tree.search_file(hash_id, 51))
+    # search_perceptual_hashes with a hash that is NOT in the library (db/vptree.py:664 takes arbitrary hashes): a noisy
+    # copy of video 20's hash must find file 21 (and the queued copy of it), a random hash nothing
+    probe = np.frombuffer(all_blobs[20], dtype=np.uint8).reshape(-1, 32).copy()
+    probe[:, 0] ^= 1
+    got = dict(tree.search_perceptual_hashes([probe.tobytes()], 51))
+    assert got.get(21) is not None and got.get(n + 1) is not None and all(1 <= d <= 51 for d in got.values())
+    assert tree.search_perceptual_hashes([rng.integers(0, 256, 32 * 5, dtype=np.uint8).tobytes()], 51) == []
+    assert tree.search_perceptual_hashes([], 51) == [] and tree.search_perceptual_hashes([b""], 51) == []
     tree.reset_search([1, 2])
     assert conn.execute("SELECT COUNT(*) FROM shape_search_cache WHERE searched_distance IS NULL").fetchone()[0] == 2
     return conn, tree
