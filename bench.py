@@ -213,7 +213,13 @@ def main():
                 d_pl = np.unpackbits(db_[planted_[:, 0]] ^ db_[planted_[:, 1]], axis=1).sum(1)
                 want = {(int(min(s, d)), int(max(s, d))) for (s, d, _), dd in zip(planted_, d_pl) if dd <= 31}
                 assert want <= set(zip(merged["i"].tolist(), merged["j"].tolist())), "planted duplicate pair missed"
-        per_rank = rdzv.allgather(json.dumps({"kernel_ms": round(float(np.mean(kms)), 3), "pairs": my_pairs[0]}).encode())
+        # every rank must hold the identical merged pair list after the exchange
+        digest = int(np.bitwise_xor.reduce(merged.view(np.uint32).astype(np.uint64) *
+                                           np.arange(1, merged.size * 4 + 1, dtype=np.uint64))) if merged.size else 0
+        per_rank = rdzv.allgather(json.dumps({"kernel_ms": round(float(np.mean(kms)), 3), "pairs": my_pairs[0],
+                                              "merged_pairs": int(merged.size), "digest": digest}).encode())
+        assert len({(json.loads(p)["merged_pairs"], json.loads(p)["digest"]) for p in per_rank}) == 1, \
+            "ranks disagree on the merged pair list"
         res = {"elapsed": elapsed, "kernel_ms": kms, "merged": merged, "per_rank": [json.loads(p) for p in per_rank],
                "bufs": (d_db, d_img, d_pairs, d_cnt), "db": db_}
         return res
