@@ -1019,7 +1019,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
     for (int q = 0; q < SQ; ++q) fifo[q] = make_uint4(0, 0, 0, 0);
 
     for (long long f = blockIdx.x; f < n; f += gridDim.x) {
-        const __amdgpu_buffer_rsrc_t rf = make_rsrc(frames + (size_t)f * frame_bytes, frame_bytes);
         const __amdgpu_buffer_rsrc_t rd = make_rsrc(out64 + (size_t)f * 4096, 4096 * sizeof(float));
         float sD = 0.0f, dl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -1031,10 +1030,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
             // 32-lane shuffle at the end of B), the lower half from the tile row above (loaded at the top of the step)
             float inB = 0.0f, inl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             float nxB = 0.0f, nxl[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the lower half's state for the NEXT step, in flight
-            if (ty > 0 && half == 0) {  // column tile 0 of this tile row
-                nxB = buf_ld(rs, (uint32_t)cl5);
-                nxl[0] = buf_ld(rs, 32u + cl5); nxl[1] = buf_ld(rs, 64u + cl5);
-                nxl[2] = buf_ld(rs, 96u + cl5); nxl[3] = buf_ld(rs, 128u + cl5);
+            {  // column tile 0 of this tile row. Loads are UNCONDITIONAL and land in the registers that carry them to their
+               // use: an index past the end of the scratch resource reads 0 and touches no memory (buffer range check),
+               // which is the state of a line's start. A load under a branch, merged with a zero from the other path,
+               // made the compiler copy the result right behind the load -- i.e. wait for it on the spot.
+                const uint32_t p0 = (ty > 0 ? 0u : (uint32_t)kWScratchFloats) + (uint32_t)cl5;
+                nxB = buf_ld(rs, p0);
+                nxl[0] = buf_ld(rs, p0 + 32u); nxl[1] = buf_ld(rs, p0 + 64u);
+                nxl[2] = buf_ld(rs, p0 + 96u); nxl[3] = buf_ld(rs, p0 + 128u);
             }
             const uint32_t rbase = (uint32_t)(kWR * ty) * row_bytes;  // byte offset of the tile row in the frame
 
@@ -1049,17 +1052,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                 // (vmcnt retires in order: a wait for these small loads also waits for every load issued before
                 // them, so they are issued one step AHEAD of their use and BEFORE this step's frame fetch -- otherwise
                 // they would cut the fetch's two steps of flight time down to a fraction of one)
-                if (half == 0) {
-                    inB = nxB;
-                    inl[0] = nxl[0]; inl[1] = nxl[1]; inl[2] = nxl[2]; inl[3] = nxl[3];
-                    nxB = 0.0f;
-                    nxl[0] = nxl[1] = nxl[2] = nxl[3] = 0.0f;
-                    if (ty > 0 && tx + 1 <= kWNX) {
-                        const uint32_t pi = (uint32_t)(tx + 1) * (5 * 32) + (uint32_t)cl5;
-                        nxB = buf_ld(rs, pi);
-                        nxl[0] = buf_ld(rs, pi + 32); nxl[1] = buf_ld(rs, pi + 64);
-                        nxl[2] = buf_ld(rs, pi + 96); nxl[3] = buf_ld(rs, pi + 128);
+                {
+                    if (half == 0) {  // the only read of last step's loads: the wait for them sits here, a step after their issue
+                        inB = nxB;
+                        inl[0] = nxl[0]; inl[1] = nxl[1]; inl[2] = nxl[2]; inl[3] = nxl[3];
                     }
+                    // unconditional, all lanes (the upper half's copies are never read): see the tile row's first load
+#ifdef HVD_ABL_NOSTATE
+                    const bool have = false;
+#else
+                    const bool have = ty > 0 && tx + 1 <= kWNX;
+#endif
+                    const uint32_t pi = (have ? (uint32_t)(tx + 1) * (5 * 32) : (uint32_t)kWScratchFloats) + (uint32_t)cl5;
+                    nxB = buf_ld(rs, pi);
+                    nxl[0] = buf_ld(rs, pi + 32); nxl[1] = buf_ld(rs, pi + 64);
+                    nxl[2] = buf_ld(rs, pi + 96); nxl[3] = buf_ld(rs, pi + 128);
                 }
                 // ---------------- A: luma + rep-1 along the row (lane = row 64ty + lane) -----------------
                 if (ty < kWNY) {
@@ -1079,16 +1086,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                         wave_mem_sync();  // ... before the arriving unit is parked there
                         if (tx < kWNX) {
                             unit_stage<CH>(stage, park, lane, pre[par]);
-                            // this half's next unit (needed two steps from now, or in the next tile row / frame)
+                            // this half's next unit (needed two steps from now, or in the next tile row / frame): ONE load
+                            // site whose frame and offset are scalar choices. Three alternative load sites merged into
+                            // pre[par] made the compiler load into temporaries and copy them over at the join -- behind an
+                            // s_waitcnt vmcnt(0), i.e. every "prefetch" was waited for the moment it was issued.
+                            long long fsel = f;
+                            uint32_t fbytes = frame_bytes, soff;
                             if (tx + 2 < kWNX) {
-                                unit_fetch<CH>(rf, rbase + (uint32_t)(32 * par) * row_bytes + (uint32_t)((tx + 2 - par) >> 1) * (2 * kWT * CH),
-                                               lane, pre[par]);
+                                soff = rbase + (uint32_t)(32 * par) * row_bytes + (uint32_t)((tx + 2 - par) >> 1) * (2 * kWT * CH);
                             } else if (ty + 1 < kWNY) {
-                                unit_fetch<CH>(rf, rbase + (uint32_t)(kWR + 32 * par) * row_bytes, lane, pre[par]);
+                                soff = rbase + (uint32_t)(kWR + 32 * par) * row_bytes;
                             } else if (f + gridDim.x < n) {
-                                unit_fetch<CH>(make_rsrc(frames + (size_t)(f + gridDim.x) * frame_bytes, frame_bytes),
-                                               (uint32_t)(32 * par) * row_bytes, lane, pre[par]);
+                                fsel = f + gridDim.x;
+                                soff = (uint32_t)(32 * par) * row_bytes;
+                            } else {  // nothing left: a resource of zero bytes returns zeros and fetches nothing
+                                fbytes = 0;
+                                soff = 0;
                             }
+#ifdef HVD_ABL_NOFETCH  // timing ablation only: every prefetch reads from a zero-byte resource
+                            fbytes = 0;
+#endif
+                            unit_fetch<CH>(make_rsrc(frames + (size_t)fsel * frame_bytes, fbytes), soff, lane, pre[par]);
                             wave_mem_sync();
                             if (half == hr) {
 #pragma unroll
@@ -1157,7 +1175,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                             for (int r = 0; r < kWC; ++r) bp[(kWC * k + r) * LD] = o[r];
                             __builtin_amdgcn_sched_barrier(0);  // one chunk of rows in registers at a time
                         }
+#ifdef HVD_ABL_NOSTATE
+                        if (false) {
+#else
                         if (half && valid) {
+#endif
                             buf_st(rs, sti, sB);
                             buf_st(rs, sti + 32, bl[0]); buf_st(rs, sti + 64, bl[1]);
                             buf_st(rs, sti + 96, bl[2]); buf_st(rs, sti + 128, bl[3]);
