@@ -320,6 +320,11 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_pdq_dct_from_lds = value;
         return HVD_OK;
     }
+    if (strcmp(key, "pdq_hash_grid") == 0) {
+        if (value < 0) return fail(HVD_ERR_ARG, "pdq_hash_grid must not be negative (0 = default)");
+        hvd::g_pdq_hash_grid = value;
+        return HVD_OK;
+    }
     if (strcmp(key, "pdq_luma_lut") == 0) {
         hvd::g_pdq_luma_lut = value;
         return HVD_OK;

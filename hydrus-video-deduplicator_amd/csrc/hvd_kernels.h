@@ -73,6 +73,7 @@ hipError_t launch_match_two_small(const uint32_t* a, uint32_t na, const uint32_t
 extern int g_pdq_dct_from_lds;
 bool pdq_dct_table_matches(const float* host_16x64);  // the kernels' compile-time DCT table vs the host's computation
 extern int g_pdq_luma_lut;
+extern int g_pdq_hash_grid;
 extern int g_pdq_dct_mode;
 extern bool g_pdq_fused_down512;
 extern int g_pdq_down512_wave;

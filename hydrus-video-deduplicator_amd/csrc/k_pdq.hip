@@ -1283,6 +1283,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
 namespace hvd {
 
 int g_pdq_dct_mode = 0;           // 0: strict mul-then-add on the VALU (default); 1: fma chain on the matrix cores
+int g_pdq_hash_grid = 0;          // A/B switch (hvd_debug_set "pdq_hash_grid"): workgroups of k_pdq_hash64, 0 = default
 int g_pdq_luma_lut = 1;           // 0: compute luma, 1: LDS table, 2: LDS table, loads in groups of 16
 // stage-1 DCT operand source (hvd_debug_set "pdq_dct_from_lds"): 0 SGPRs, 1 LDS, 2 literals, 3 (default) by batch size --
 // literals from 64k frames on (+9 % at 400k frames: full-rate multiplies), SGPRs below (the unrolled 21 KB of code cost
@@ -1305,6 +1306,7 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
     const int64_t groups = (n + kWaves - 1) / kWaves;
     const int64_t max_grid = 256 * 7;  // 7 workgroups/CU fit by LDS (21.8 KB each)
     dim3 grid((unsigned)(groups < max_grid ? groups : max_grid));
+    if (g_pdq_hash_grid > 0) grid.x = (unsigned)(groups < g_pdq_hash_grid ? groups : g_pdq_hash_grid);
     if (g_pdq_dct_mode == 1) {
         if (kind == 0)
             hipLaunchKernelGGL(k_pdq_hash64_fma<0>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
