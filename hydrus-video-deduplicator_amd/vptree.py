@@ -48,8 +48,11 @@ class VpTreeManager:
 
     # ---- the parts of the reference API that maintained the tree: cheap or no-ops here ------------------------
     def add_leaf(self, perceptual_hash_id, perceptual_hash):
-        """A new perceptual hash joins the library (db/vptree.py:155-283): appended; compared at the next search."""
-        self._load()
+        """A new perceptual hash joins the library (db/vptree.py:155-283): appended; compared at the next search.
+        The reference creates a fresh manager per inserted file (db/DedupeDB.py:303-304) and inserts the hash row before
+        calling this, so an instance that has not read the library yet has nothing to do: its first search reads the row."""
+        if not self._loaded:
+            return
         if perceptual_hash_id in self._index:
             return
         self._append(int(perceptual_hash_id), bytes(perceptual_hash))

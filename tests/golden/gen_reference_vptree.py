@@ -48,11 +48,63 @@ def match_hash_bytes(a: bytes, b: bytes, tol: int) -> float:
 stub = types.ModuleType("hvdaccelerators")
 vp = types.ModuleType("hvdaccelerators.vpdq")
 vp.matchHashBytes = match_hash_bytes
+vp.matchHash = lambda q, t, tol: match_hash_bytes(q.bytes, t.bytes, tol)
+vp.VpdqHash = hvd_amd.VpdqHash          # the value type is host-side Python in this repo: no GPU involved
+vp.VideoHasher = object                 # never constructed here (decoding needs PyAV)
 stub.vpdq = vp
 sys.modules["hvdaccelerators"] = stub
 sys.modules["hvdaccelerators.vpdq"] = vp
+sys.modules.setdefault("av", types.ModuleType("av"))  # imported at module level by vpdqpy.py; never used here
 
+from hydrusvideodeduplicator import dedup  # noqa: E402
 from hydrusvideodeduplicator.db import DedupeDB, vptree  # noqa: E402
+
+
+class _FakeHydrus:
+    """Stands in for hydrus_api.Client: records what dedup.mark_videos_as_duplicates sends (dedup.py:385-394)."""
+
+    def __init__(self):
+        self.relationships = []
+
+    def set_file_relationships(self, rels):
+        self.relationships.extend((r["hash_a"], r["hash_b"]) for r in rels)
+
+
+class _FakeClient:
+    def __init__(self):
+        self.client = _FakeHydrus()
+
+
+def run_reference_pipeline(blobs, file_hashes, threshold, tree_factory=None):
+    """The reference's OWN process_phashed_file_queue + find_potential_duplicates (dedup.py:396-502) on a fresh database.
+    tree_factory: None = the reference's VpTreeManager; else a callable db -> manager that replaces it in both modules
+    that construct one (dedup.py and db/DedupeDB.py) -- the import swap of INTEGRATION.md 3c."""
+    saved = (dedup.vptree.VpTreeManager, DedupeDB.VpTreeManager)
+    try:
+        if tree_factory is not None:
+            dedup.vptree.VpTreeManager = tree_factory
+            DedupeDB.VpTreeManager = tree_factory
+        # the reference keeps a process-wide cache of temp-table names that belongs to ONE connection ("do this once per
+        # program run", db/vptree.py:136-149): a fresh database needs a fresh cache
+        vptree.TemporaryIntegerTableNameCache()
+        with tempfile.TemporaryDirectory() as tmp:
+            db = DedupeDB.DedupeDb(Path(tmp), "videohashes.sqlite")
+            db.init_connection()
+            db.create_tables()
+            for fh, blob in zip(file_hashes, blobs):
+                db.add_to_phashed_files_queue(fh, blob)
+            db.commit()
+            client = _FakeClient()
+            dd = dedup.HydrusVideoDeduplicator(db, client)
+            dd.threshold = threshold
+            dd.process_phashed_file_queue()
+            returned = dd.find_potential_duplicates()
+            db.commit()
+            cache = db.execute("SELECT hash_id, searched_distance FROM shape_search_cache ORDER BY hash_id").fetchall()
+            db.close()
+        return client.client.relationships, returned, cache
+    finally:
+        dedup.vptree.VpTreeManager, DedupeDB.VpTreeManager = saved
 
 
 def build_library(n_videos=90, seed=31):
@@ -138,6 +190,31 @@ def main():
         conv_queue = [bytes(r[0]) for r in db.execute("SELECT phash FROM phashed_file_queue ORDER BY file_hash").fetchall()]
         out["upgraded_version"] = np.array(db.get_version())
         db.close()
+
+    # ---- the reference's real pipeline loop: its own tree, then THIS repo's facade swapped in -------------------------
+    import hvd_amd.vptree as our_vptree
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_sqlite_adapter import OracleMatcher
+
+    rel_ref, ret_ref, cache_ref = run_reference_pipeline(blobs, file_hashes, 50.0)
+    rel_fac, ret_fac, cache_fac = run_reference_pipeline(
+        blobs, file_hashes, 50.0, tree_factory=lambda db: our_vptree.VpTreeManager(db, matcher=OracleMatcher(O)))
+    assert cache_ref == cache_fac and all(sd == 51 for _, sd in cache_ref)
+    assert set(rel_ref) <= set(rel_fac), "the facade must report every pair the reference's tree reports"
+    # the facade's answer is the brute-force truth, found from both sides
+    truth = set()
+    for a in range(len(blobs)):
+        for b in range(len(blobs)):
+            if a != b and int(match_hash_bytes(blobs[a], blobs[b], 31)) >= 50:
+                truth.add((file_hashes[a], file_hashes[b]))
+    assert set(rel_fac) == truth and len(rel_fac) == len(truth) and ret_fac == len(truth) // 2
+    out["pipeline_pairs_reference_tree"] = np.array(sorted(set(rel_ref)))
+    out["pipeline_pairs_facade"] = np.array(sorted(set(rel_fac)))
+    out["pipeline_return_reference_tree"] = np.int64(ret_ref)
+    out["pipeline_return_facade"] = np.int64(ret_fac)
+    print(f"reference pipeline: its own tree reports {len(set(rel_ref))} directed pairs (returns {ret_ref}); with the facade "
+          f"swapped in {len(set(rel_fac))} = brute force (returns {ret_fac})")
 
     def pack(blist):
         lens = np.array([len(b) for b in blist], dtype=np.int64)
