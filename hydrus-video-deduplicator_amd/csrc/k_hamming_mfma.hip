@@ -548,6 +548,7 @@ static bool mfma_form(int variant, MfmaForm* f) {
         case 10: *f = {4, 4, 4}; return true;
         case 11: *f = {4, 2, 2}; return true;
         case 12: *f = {4, 4, 2}; return true;
+        case 14: *f = {8, 4, 2}; return true;  // experiment: register form with 8 tiles per wave (2 waves/SIMD)
         default: return false;
     }
 }
@@ -621,6 +622,7 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
         case 10: return launch_form<4, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 10u, s);
         case 11: return launch_form<4, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 11u, s);
         case 12: return launch_form<4, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 12u, s);
+        case 14: return launch_form<8, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 14u, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -672,6 +674,7 @@ static int effective_variant(int variant, uint32_t max_dist) {
     if (max_dist >= 64u) {
         if (variant == 9 || variant == 13) return 8;
         if (variant == 11 || variant == 12) return 10;
+        if (variant == 14) return 8;
     }
     return variant;
 }

@@ -242,9 +242,9 @@ def _run_variant(gpu, hvd, db, variant, max_dist=31, group=None, cap=1 << 16):
     return hvd.multigpu.merge_pairs([d_pairs.to_array(gpu.PAIR_DTYPE, cnt)])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14])
 def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
-    """Popcount (0..6) and FP4-MFMA (8..13) forms produce the identical pair list."""
+    """Popcount (0..6) and FP4-MFMA (8..14) forms produce the identical pair list."""
     n = 20000
     db, _ = hvd.synth.hash_db(n, seed=53, plant_fraction=0.01)
     want = oracle.allpairs(db, 31, num_threads=8)
