@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the VPDQ hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py spawns its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W      (any launcher that sets RANK / WORLD_SIZE)
 
 A "step" is one brute-force all-pairs pass (256-bit Hamming, tolerance 31) over a synthetic
 hash DB resident in HBM, including the candidate-pair exchange: BASELINE.json configs[2]
@@ -100,20 +100,85 @@ def load_traffic(key):
         return None
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher environment: spawn the N ranks ourselves (one process per
+    GPU: RANK = LOCAL_RANK = r, WORLD_SIZE = N, a free MASTER_PORT, a private rendezvous file), forward rank 0's
+    single JSON line, return non-zero if ANY rank fails (the others are then terminated, not left hanging in a
+    barrier). No torch anywhere; `python -m torch.distributed.run ... bench.py` keeps working as before."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    rdzv_dir = tempfile.mkdtemp(prefix="hvd_bench_")  # 0700, ours alone
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HVD_RDZV_FILE=os.path.join(rdzv_dir, "rdzv"))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+        import threading
+
+        box = {}
+        reader = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()), daemon=True)
+        reader.start()
+        rcs = [None] * n
+        failed = None
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p.poll()
+                    if rcs[r] not in (None, 0) and failed is None:
+                        failed = r
+            if failed is not None:
+                break
+            time.sleep(0.05)
+        if failed is not None:
+            print(f"[bench] rank {failed} exited with {rcs[failed]}; terminating the other ranks", file=sys.stderr)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rcs[failed] if rcs[failed] > 0 else 1
+        reader.join(timeout=10)
+        lines = [ln for ln in (box.get("out") or b"").decode().splitlines() if ln.startswith("{")]
+        if len(lines) != 1:
+            print(f"[bench] rank 0 printed {len(lines)} JSON lines (expected 1)", file=sys.stderr)
+            return 1
+        sys.stdout.write(lines[0] + "\n")
+        sys.stdout.flush()
+        return 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(rdzv_dir, ignore_errors=True)
+
+
 def main():
+    args = parse()
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     # Native libraries (RCCL) print banners on fd 1; the contract is ONE JSON line on stdout.
     # Keep the real stdout aside and point fd 1 at stderr for everything else.
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+        args.gpus = world  # a launcher's WORLD_SIZE wins over the flag
 
     import hvd_amd
     from hvd_amd import _lib as L
@@ -395,6 +460,14 @@ def main():
                    "pairs_found": int(len(merged))},
         "roofline": roofline,
         "per_rank": head["per_rank"],
+        # which block is the scaling curve: the top-level `value` at every N
+        "scale_metric": {
+            "weak": f"`value`: all-pairs comparisons/s over n = {args.hashes}*sqrt(N) hashes (comparisons per GPU fixed at "
+                    f"{args.hashes * (args.hashes - 1) // 2:.4g}; BASELINE configs[2] at N=1); `config4.value` is the strong-"
+                    "scaling companion (BASELINE configs[3], 10M hashes, fixed total work) measured in the same run",
+            "strong": "`value`: all-pairs comparisons/s over BASELINE configs[2] (fixed total work) at every N",
+            "cfg4": "`value`: all-pairs comparisons/s over BASELINE configs[3] (10M hashes, fixed total work) at every N",
+        }[args.mode],
     }
     if cfg4:
         out["config4"] = cfg4

@@ -5,28 +5,54 @@ The data path never goes through here: candidate pairs, video-level keys and has
 exchanged by RCCL over xGMI inside the C-ABI (`hvd_comm_*`). This is the control channel only, so
 plain sockets are enough -- and they keep `torch` out of the product (north_star: "no PyTorch").
 
-Rank 0 listens on an ephemeral loopback port and publishes it in a file that all ranks can
-derive: ``$HVD_RDZV_FILE`` or ``/tmp/hvd_rdzv_<MASTER_PORT>_<parent pid>`` -- the workers that
+Rank 0 listens on an ephemeral loopback port and publishes "port token" in a file that all ranks can
+derive: ``$HVD_RDZV_FILE`` or ``<per-user dir>/hvd_rdzv_<MASTER_PORT>_<parent pid>`` -- the workers that
 `python -m torch.distributed.run` (or any other launcher) starts share their parent process, and
 MASTER_PORT distinguishes concurrent launches. Every collective is one round trip through rank 0.
+
+Local hardening: the per-user directory is ``$XDG_RUNTIME_DIR`` or ``<tmp>/hvd_rdzv_<uid>`` (0700, must be
+owned by this user and not a symlink); the file is created O_CREAT|O_EXCL|O_NOFOLLOW with mode 0600 and carries a
+random 128-bit token that a peer must echo in its hello -- another local user can neither plant the file nor
+claim a rank; the handshake has its own short timeout, so a stale file whose port was reused costs seconds,
+not the collective timeout.
 """
 
 from __future__ import annotations
 
 import os
+import secrets
 import socket
+import stat
 import struct
 import tempfile
 import time
 
-_MAGIC = b"HVDRDZV1"
+_MAGIC = b"HVDRDZV2"
+_TOKEN_BYTES = 16
+_HANDSHAKE_TIMEOUT = 5.0
+
+
+def _user_dir() -> str:
+    """A directory only this user can write: $XDG_RUNTIME_DIR, else <tmp>/hvd_rdzv_<uid> (created 0700, verified)."""
+    xdg = os.environ.get("XDG_RUNTIME_DIR")
+    if xdg and os.path.isdir(xdg) and os.access(xdg, os.W_OK):
+        return xdg
+    d = os.path.join(tempfile.gettempdir(), f"hvd_rdzv_{os.getuid()}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"rendezvous directory {d} is not a private directory of this user")
+    return d
 
 
 def _default_file() -> str:
     explicit = os.environ.get("HVD_RDZV_FILE")
     if explicit:
         return explicit
-    return os.path.join(tempfile.gettempdir(), f"hvd_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    return os.path.join(_user_dir(), f"hvd_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
 
 
 def _recv_exact(sock: socket.socket, n: int) -> bytes:
@@ -77,26 +103,34 @@ class Rendezvous:
         ls.listen(self.world)
         ls.settimeout(self.timeout)
         self._listener = ls
+        token = secrets.token_bytes(_TOKEN_BYTES)
         tmp = f"{self.path}.{os.getpid()}.tmp"
-        with open(tmp, "w") as f:
-            f.write(str(ls.getsockname()[1]))
-        os.replace(tmp, self.path)  # atomic: readers see nothing or the whole port number
+        try:
+            os.unlink(tmp)
+        except FileNotFoundError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "w") as f:
+            f.write(f"{ls.getsockname()[1]} {token.hex()}")
+        os.replace(tmp, self.path)  # atomic: readers see nothing or the whole record
         peers: list[socket.socket | None] = [None] * self.world
         deadline = time.monotonic() + self.timeout
         while any(p is None for p in peers[1:]):
             if time.monotonic() > deadline:
                 raise TimeoutError(f"rendezvous: {sum(p is None for p in peers[1:])} rank(s) never connected")
             conn, _ = ls.accept()
-            conn.settimeout(self.timeout)
+            conn.settimeout(_HANDSHAKE_TIMEOUT)
             try:
-                hello = _recv_exact(conn, len(_MAGIC) + 8)
-            except (ConnectionError, socket.timeout):
+                hello = _recv_exact(conn, len(_MAGIC) + _TOKEN_BYTES + 8)
+            except (ConnectionError, socket.timeout, OSError):
                 conn.close()
                 continue
-            r, w = struct.unpack("<II", hello[len(_MAGIC):])
-            if hello[: len(_MAGIC)] != _MAGIC or w != self.world or not (0 < r < self.world) or peers[r] is not None:
+            r, w = struct.unpack("<II", hello[len(_MAGIC) + _TOKEN_BYTES:])
+            if (hello[: len(_MAGIC)] != _MAGIC or not secrets.compare_digest(hello[len(_MAGIC): len(_MAGIC) + _TOKEN_BYTES], token)
+                    or w != self.world or not (0 < r < self.world) or peers[r] is not None):
                 conn.close()
                 continue
+            conn.settimeout(self.timeout)
             conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             conn.sendall(_MAGIC)
             peers[r] = conn
@@ -107,12 +141,20 @@ class Rendezvous:
         last = None
         while time.monotonic() < deadline:
             try:
-                port = int(open(self.path).read().strip())
-                s = socket.create_connection(("127.0.0.1", port), timeout=5.0)
-                s.settimeout(self.timeout)
+                fd = os.open(self.path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+                with os.fdopen(fd) as f:
+                    if os.fstat(f.fileno()).st_uid != os.getuid():
+                        raise PermissionError(f"{self.path} belongs to another user")
+                    port_s, token_s = f.read().split()
+                token = bytes.fromhex(token_s)
+                if len(token) != _TOKEN_BYTES:
+                    raise ValueError("malformed rendezvous record")
+                s = socket.create_connection(("127.0.0.1", int(port_s)), timeout=_HANDSHAKE_TIMEOUT)
+                s.settimeout(_HANDSHAKE_TIMEOUT)  # a stale file whose port was reused must not cost the collective timeout
                 s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                s.sendall(_MAGIC + struct.pack("<II", self.rank, self.world))
+                s.sendall(_MAGIC + token + struct.pack("<II", self.rank, self.world))
                 if _recv_exact(s, len(_MAGIC)) == _MAGIC:
+                    s.settimeout(self.timeout)
                     self._up = s
                     return
                 s.close()

@@ -50,11 +50,23 @@ def convert_old_vpdq_to_new(old_vpdq_phash_json) -> bytes:
 
 
 def is_old_format(phash) -> bool:
-    """JSON text (str, or bytes starting with '[') instead of a multiple of 32 raw bytes."""
+    """Pre-0.10.0 JSON text instead of raw 32-byte frame hashes. The reference keys its migration on the DB version
+    table (db/DedupeDB.py:528-584); rows are judged here by CONTENT so that a half-migrated or foreign file still
+    reads correctly -- and independently of the length: a JSON blob whose byte count happens to be a multiple of 32
+    (about 1 in 32 of them) is still JSON. The test: a str, or bytes that are '[' ... ']', pure ASCII, and parse
+    as a JSON list of strings. Raw hash bytes pass that with probability < 2^-64 (every byte would have to be ASCII)."""
     if isinstance(phash, str):
         return True
     b = bytes(phash)
-    return len(b) % 32 != 0 and b[:1] == b"["
+    if len(b) < 2 or b[:1] != b"[" or b[-1:] != b"]" or not b.isascii():
+        return False
+    import json
+
+    try:
+        parsed = json.loads(b.decode("ascii"))
+    except ValueError:
+        return False
+    return isinstance(parsed, list) and all(isinstance(x, str) for x in parsed)
 
 
 def upgrade_old_phashes(conn: sqlite3.Connection) -> int:

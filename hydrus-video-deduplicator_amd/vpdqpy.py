@@ -19,20 +19,65 @@ DOWNSCALE_DIMENSIONS = 512
 VpdqHash = vpdq.VpdqHash
 
 
+def hashed_frame_stride(average_rate) -> int:
+    """Every how-many-th decoded frame the reference hashes (vpdqpy.py:72-77): ``round(average_rate)`` of the
+    stream's average frame rate -- Python's round, so a Fraction of exactly k + 1/2 goes to the even neighbour,
+    as it does there -- and 1 (every frame) when the rate is None or below 1 (small GIFs)."""
+    if average_rate is None or average_rate < 1:
+        return 1
+    return round(average_rate)
+
+
+def select_frames(frames, average_rate, bad_frame_errors: tuple = ()):
+    """The frame-selection rule of ``frame_extract_pyav`` (vpdqpy.py:72-77,85-101) for a decoder-side caller:
+    yield the frames whose DECODE index is a multiple of ``hashed_frame_stride(average_rate)``.
+
+    `frames` is any iterable of decoded frames in decode order. An exception of a type listed in
+    `bad_frame_errors` (the reference: ``av.error.InvalidDataError``) raised while fetching a frame skips that
+    frame but still advances the index (vpdqpy.py:99-101), so the frames after it keep their phase. Which frames
+    are hashed is part of the video hash: feed ``Vpdq.computeHash`` / ``VideoHasher.hash_frame`` from this."""
+    stride = hashed_frame_stride(average_rate)
+    it = iter(frames)
+    frame_index = 0
+    while True:
+        try:
+            frame = next(it)
+            if frame_index % stride == 0:
+                yield frame
+            frame_index += 1
+        except StopIteration:
+            break
+        except bad_frame_errors:
+            frame_index += 1
+
+
+def selected_frame_indices(n_decoded: int, average_rate) -> np.ndarray:
+    """Decode indices `select_frames` keeps out of n_decoded good frames (array form: ``frames[idx]``)."""
+    return np.arange(0, max(0, int(n_decoded)), hashed_frame_stride(average_rate), dtype=np.int64)
+
+
 class Vpdq:
     @staticmethod
     def match_hash(query_features: VpdqHash, target_features: VpdqHash, distance_tolerance: float = 31.0):
         """Get the similarity of two videos by comparing their list of features (vpdqpy.py:49-56)."""
         return vpdq.matchHash(query_features, target_features, int(distance_tolerance))
 
+    select_frames = staticmethod(select_frames)
+
     @staticmethod
-    def computeHash(frames, num_threads: int = 0, width: int | None = None, height: int | None = None) -> VpdqHash:
+    def computeHash(frames, num_threads: int = 0, width: int | None = None, height: int | None = None,
+                    average_rate=None, all_decoded_frames: bool = False) -> VpdqHash:
         """Perceptually hash a video given its decoded frames (vpdqpy.py:103-119 minus decode).
 
         frames: uint8[n,h,w,3] / uint8[n,h,w] array, or an iterable of per-frame byte strings
-        (then width/height default to DOWNSCALE_DIMENSIONS, as the reference passes)."""
+        (then width/height default to DOWNSCALE_DIMENSIONS, as the reference passes). By default `frames` are
+        the frames to hash (what ``frame_extract_pyav`` yields); with ``all_decoded_frames=True`` they are EVERY
+        decoded frame and the reference's selection rule is applied first (``select_frames(frames, average_rate)``)."""
         if frames is None:
             raise ValueError
+        if all_decoded_frames and not isinstance(frames, (bytes, bytearray, memoryview, str, os.PathLike)):
+            frames = (frames[selected_frame_indices(frames.shape[0], average_rate)] if isinstance(frames, np.ndarray)
+                      else select_frames(frames, average_rate))
         if isinstance(frames, (bytes, bytearray, memoryview, str, os.PathLike)):
             # the reference's caller passes the ENCODED video (dedup.py:76) and decodes it with PyAV; decoding is
             # out of scope here, and iterating a bytes object would silently hash garbage

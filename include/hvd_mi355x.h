@@ -251,8 +251,9 @@ int hvd_timer_start(void);
 int hvd_timer_stop(float* out_ms);
 
 /* ----------------------------------------------- multi-GPU exchange ------ */
-/* One process per GPU; rank 0 creates the id, the launcher distributes it (bench.py
- * uses torch.distributed's store for that), every rank calls hvd_comm_init. */
+/* One process per GPU; rank 0 creates the id, the caller's control channel hands it to the other ranks
+ * (hvd_amd.rendezvous: a loopback TCP star -- no torch; bench.py and hvd_amd.multigpu.connect_rccl use it),
+ * every rank calls hvd_comm_init (collective). */
 int hvd_comm_unique_id(uint8_t out_id[HVD_UNIQUE_ID_BYTES]);
 int hvd_comm_init(const uint8_t id[HVD_UNIQUE_ID_BYTES], int rank, int world);
 /* RCCL all-gather over xGMI of each rank's candidate pairs: counts first, then the

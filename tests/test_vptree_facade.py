@@ -137,6 +137,39 @@ def test_old_format_phashes_are_converted_not_refused(hvd):
     assert conn.execute("SELECT COUNT(*) FROM shape_perceptual_hash_map").fetchone()[0] == 2
 
 
+def test_old_format_json_whose_length_is_a_multiple_of_32_is_still_json(hvd):
+    """a JSON blob stored as BYTES with len % 32 == 0 was classified as raw hashes and searched as garbage.
+    The decision must not depend on the length."""
+    import sqlite3
+
+    A = hvd.sqlite_adapter
+    rng = np.random.default_rng(10)
+    hit = 0
+    for n_frames in range(1, 40):
+        for width in range(1, 8):  # the frame-number field varies the length
+            frames = rng.integers(0, 256, (n_frames, 32), dtype=np.uint8)
+            old = json.dumps([f"{bytes(f[::-1]).hex()},{99},{10 ** width + k}" for k, f in enumerate(frames)]).encode()
+            assert A.is_old_format(old) and A.is_old_format(old.decode())
+            if len(old) % 32 == 0:
+                hit += 1
+                conn = sqlite3.connect(":memory:")
+                for stmt in SCHEMA:
+                    conn.execute(stmt)
+                conn.execute("INSERT INTO files VALUES (1, 'aa')")
+                conn.execute("INSERT INTO shape_perceptual_hashes VALUES (1, ?)", (old,))
+                conn.execute("INSERT INTO shape_perceptual_hash_map VALUES (1, 1)")
+                conn.execute("INSERT INTO shape_search_cache VALUES (1, NULL)")
+                assert A.load_library(conn).frames.tobytes() == frames.tobytes()
+                assert A.upgrade_old_phashes(conn) == 1
+                assert bytes(conn.execute("SELECT phash FROM shape_perceptual_hashes").fetchone()[0]) == frames.tobytes()
+    assert hit >= 3  # the case is really exercised
+    # raw hashes that merely start with '[' and end with ']' are not JSON
+    raw = bytes([0x5B]) + bytes(rng.integers(0, 256, 62, dtype=np.uint8)) + bytes([0x5D])
+    assert not A.is_old_format(raw)
+    assert not A.is_old_format(b"[" + b"a" * 30 + b"]")  # ASCII, bracketed, 32 bytes, but not JSON
+    assert not A.is_old_format(b"[1, 2, 3, 4, 5, 6, 7, 8, 9, 10 ]")  # JSON, 32 bytes, but not a list of strings
+
+
 def test_compute_hash_rejects_encoded_video_input(hvd):
     """The reference's caller passes the encoded file (dedup.py:76); decoding is out of scope and must say so."""
     for bad in (b"\x00" * 100, "video.mp4", bytearray(12)):
