@@ -100,6 +100,80 @@ def load_traffic(key):
         return None
 
 
+def videohasher_stream_leg(lib, L, synth, vpdq):
+    """The reference's actual hashing call pattern (vpdqpy/vpdqpy.py:113-119): ONE VideoHasher per video, one
+    hash_frame(...) per frame, finish() per video, videos strictly one after the other -- through the drop-in Python
+    class, host frames in, VpdqHash out, PCIe and every Python call inside the timed region. Four feeds:
+      bytes         hash_frame(bytes)            what the unchanged reference loop passes (a 786 KB memcpy into the ring)
+      buffer        hash_frame(ndarray row)      any buffer object, same memcpy, no bytes object
+      acquire_copy  acquire_frame() + np.copyto + commit_frame()   a decoder writing at memcpy speed into the pinned slot
+      acquire_only  acquire_frame() + commit_frame()               the feed's own ceiling: slot contents left as the previous
+                                                                   video wrote them (same frames, same positions)
+    Every video's hash is compared with the batch entry point's. Next to it: a pinned host->device bandwidth probe taken
+    in the same run; `h2d_frac` = frame bytes/s over that probe."""
+    out = {}
+    nb = 256 << 20
+    hp = C.c_void_p()
+    L.check(lib.hvd_host_malloc(C.byref(hp), nb))
+    C.memset(hp, 1, nb)
+    d = L.DeviceBuffer(nb)
+    rates = []
+    for _ in range(7):
+        t = time.perf_counter()
+        L.check(lib.hvd_memcpy_h2d(d.ptr, hp, nb))
+        rates.append(nb / (time.perf_counter() - t) / 1e9)
+    d.free()
+    L.check(lib.hvd_host_free(hp))
+    h2d = float(np.median(rates[1:]))
+    out["h2d_probe"] = {"GBps": round(h2d, 2), "GBps_best": round(max(rates), 2),
+                        "what": "256 MiB hipMemcpy from page-locked host memory (hvd_host_malloc), median of 6"}
+    frames_per_video = 300
+    for name, (w, h, ch, n_videos) in (("512x512_rgb24", (512, 512, 3, 12)), ("64x64_gray", (64, 64, 1, 60))):
+        if ch == 3:
+            distinct = synth.frames_rgb(16, seed=6)
+        else:
+            distinct = synth.frames_gray(frames_per_video, seed=2)
+        video = np.ascontiguousarray(distinct[np.arange(frames_per_video) % distinct.shape[0]])
+        hh, qq = vpdq.hash_frames(video)
+        want = hh[qq >= 31].tobytes()
+        fb = video[0].nbytes
+        as_bytes = [video[k].tobytes() for k in range(frames_per_video)]
+        rows = video.reshape(frames_per_video, -1)
+        res = {"frames_per_video": frames_per_video, "videos": n_videos, "frame_bytes": fb,
+               "frames_kept_per_video": len(want) // 32}
+
+        def run(feed):
+            hs = vpdq.VideoHasher(1, w, h, 0)
+            if feed == "bytes":
+                for f in as_bytes:
+                    hs.hash_frame(f)
+            elif feed == "buffer":
+                for k in range(frames_per_video):
+                    hs.hash_frame(rows[k])
+            elif feed == "acquire_copy":
+                for k in range(frames_per_video):
+                    np.copyto(hs.acquire_frame(ch), video[k])
+                    hs.commit_frame()
+            else:
+                for k in range(frames_per_video):
+                    hs.acquire_frame(ch)
+                    hs.commit_frame()
+            return hs.finish()
+
+        for feed in ("bytes", "buffer", "acquire_copy", "acquire_only"):
+            assert run("acquire_copy" if feed == "acquire_only" else feed).bytes == want  # warm-up, fills the slots
+            t = time.perf_counter()
+            for _ in range(n_videos):
+                got = run(feed)
+                assert got.bytes == want, f"VideoHasher({feed}) differs from the batch entry point"
+            dt = time.perf_counter() - t
+            fps = n_videos * frames_per_video / dt
+            res[feed] = {"frames_per_s": sig(fps), "GBps": round(fps * fb / 1e9, 2), "h2d_frac": round(fps * fb / 1e9 / h2d, 3),
+                         "ms_per_video": round(dt / n_videos * 1e3, 3), "us_per_frame": round(dt / n_videos / frames_per_video * 1e6, 2)}
+        out[name] = res
+    return out
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` with no launcher environment: spawn the N ranks ourselves (one process per
     GPU: RANK = LOCAL_RANK = r, WORLD_SIZE = N, a free MASTER_PORT, a private rendezvous file), forward rank 0's
@@ -579,6 +653,8 @@ def main():
                          "traffic": load_traffic(f"down512w_rgb_n{n_rgb}"),
                          "note": "algorithmic bytes = 786432 in + 36 out per frame; `traffic` = PMC bytes per launch "
                                  "(FETCH_SIZE x2 + WRITE_SIZE, profiles/)"}}
+
+        out["videohasher_stream"] = videohasher_stream_leg(lib, L, synth, hvd_amd.vpdq)
 
         # sustained: the headline pass back to back with no host synchronisation in between (power/thermal steady state)
         if args.sustain_seconds > 0:

@@ -35,6 +35,7 @@ SIGNATURES = {
     "hvd_shutdown": (_int, []),
     "hvd_last_error": (_int, [C.c_char_p, _sz]),
     "hvd_dct_matrix": (_int, [_vp]),
+    "hvd_dct_matrix_libm": (_int, [_vp]),
     "hvd_pdq_hash_frames_gray_u8": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "hvd_pdq_hash_frames_rgb24_u8": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "hvd_allpairs_hamming256": (_int, [_vp, _i64, _vp, _int, _vp, _i64, C.POINTER(_i64)]),
@@ -51,6 +52,8 @@ SIGNATURES = {
     "hvd_hasher_destroy": (_int, [_vp]),
     "hvd_dev_malloc": (_int, [C.POINTER(_vp), _sz]),
     "hvd_dev_free": (_int, [_vp]),
+    "hvd_host_malloc": (_int, [C.POINTER(_vp), _sz]),
+    "hvd_host_free": (_int, [_vp]),
     "hvd_dev_memset": (_int, [_vp, _int, _sz]),
     "hvd_memcpy_h2d": (_int, [_vp, _vp, _sz]),
     "hvd_memcpy_d2h": (_int, [_vp, _vp, _sz]),

@@ -160,6 +160,12 @@ int hvd_device_count(int* out_n) {
 
 int hvd_dct_matrix(float* out) {
     if (!out) return fail(HVD_ERR_ARG, "out is NULL");
+    hvd::pdq_dct_table_copy(out);
+    return HVD_OK;
+}
+
+int hvd_dct_matrix_libm(float* out) {
+    if (!out) return fail(HVD_ERR_ARG, "out is NULL");
     fill_dct(out);
     return HVD_OK;
 }
@@ -188,10 +194,10 @@ int hvd_init(int device) {
         else return fail(HVD_ERR_ARG, "HVD_PDQ_DCT_MODE=%s: expected strict or fma", m);
     }
     HIP_TRY(hipSetDevice(device));
-    fill_dct(g.h_dct);
-    if (!hvd::pdq_dct_table_matches(g.h_dct))  // the hash kernel carries the matrix as instruction literals
-        return fail(HVD_ERR_STATE, "this host's libm computes a DCT matrix that differs from the table compiled into the "
-                                   "kernels (scripts/gen_dct_table.py): refusing to produce different hashes");
+    // The DCT matrix is a constant of the algorithm: the table compiled into the kernels (csrc/dct_table.inc, generated
+    // once by scripts/gen_dct_table.py) is authoritative for the literal AND the operand forms of the hash kernel, so the
+    // hashes do not depend on this host's libm. tests/ compare it with hvd_dct_matrix_libm() and with the oracle.
+    hvd::pdq_dct_table_copy(g.h_dct);
     hipError_t e = hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&g.ev0);
     if (e == hipSuccess) e = hipEventCreate(&g.ev1);
@@ -231,6 +237,7 @@ int hvd_shutdown(void) {
     for (void* p : g.scr)
         if (p) (void)hipFree(p);
     if (g.m_pin) (void)hipHostFree(g.m_pin);
+    hvd::stream_release_cache();
     hvd::mfma_release();
     g.~Ctx();
     new (&g) Ctx();
@@ -243,6 +250,19 @@ int hvd_dev_malloc(void** out_ptr, size_t bytes) {
     if (int rc = need_ready()) return rc;
     if (!out_ptr) return fail(HVD_ERR_ARG, "out_ptr is NULL");
     HIP_TRY(hipMalloc(out_ptr, bytes ? bytes : 1));
+    return HVD_OK;
+}
+
+int hvd_host_malloc(void** out_ptr, size_t bytes) {
+    if (int rc = need_ready()) return rc;
+    if (!out_ptr) return fail(HVD_ERR_ARG, "out_ptr is NULL");
+    HIP_TRY(hipHostMalloc(out_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return HVD_OK;
+}
+
+int hvd_host_free(void* h_ptr) {
+    if (int rc = need_ready()) return rc;
+    if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
     return HVD_OK;
 }
 

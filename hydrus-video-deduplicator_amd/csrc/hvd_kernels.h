@@ -38,6 +38,7 @@ hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_
                              const int32_t* d_group_t, hipStream_t s);
 hipError_t mfma_select_buffer(uint32_t** out);  // [0] = form the auto variant ran last, [1] = probe survivors
 void mfma_release();
+void stream_release_cache();  // hvd_stream.cpp: free the parked hasher slot sets (hvd_shutdown)
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 
 // Video-level reduction and quality compaction (k_vmatch.hip).
@@ -71,6 +72,7 @@ hipError_t launch_match_two_small(const uint32_t* a, uint32_t na, const uint32_t
 // kind 0: gray u8 64x64 frames; kind 1: float 64x64 buffers (output of the
 // down-sampler). d_in strides are implied by kind.
 extern int g_pdq_dct_from_lds;
+void pdq_dct_table_copy(float* out_16x64);               // the compiled-in DCT matrix (csrc/dct_table.inc): authoritative
 bool pdq_dct_table_matches(const float* host_16x64);  // the kernels' compile-time DCT table vs the host's computation
 extern int g_pdq_luma_lut;
 extern int g_pdq_hash_grid;

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "hvd_kernels.h"
@@ -81,11 +82,17 @@ static int submit(hvd_hasher* hs, Slot& s) {
     return HVD_OK;
 }
 
-extern "C" {
+// The reference creates one VideoHasher per video (vpdqpy/vpdqpy.py:113) and videos come strictly one after the
+// other (dedup.py:346-352). Pinning and unpinning 3 x 64 MiB of host memory per video costs more than hashing a
+// short video, so a destroyed hasher's slots (pinned staging, device buffers, streams, events) are PARKED and the
+// next hvd_hasher_create with the same geometry takes them over. At most kMaxParked sets are kept (a GUI worker
+// and the CLI never run more than one or two hashers at a time); hvd_shutdown() releases them.
+namespace {
+constexpr size_t kMaxParked = 2;
+std::mutex g_park_mu;
+std::vector<hvd_hasher*> g_parked;
 
-int hvd_hasher_destroy(hvd_hasher* hs) {
-    if (!hs) return HVD_OK;
-    (void)hvd::api_bind_device();
+void free_hasher(hvd_hasher* hs) {
     for (Slot& s : hs->slot) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         if (s.h_frames) (void)hipHostFree(s.h_frames);
@@ -99,6 +106,43 @@ int hvd_hasher_destroy(hvd_hasher* hs) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     delete hs;
+}
+}  // namespace
+
+namespace hvd {
+void stream_release_cache() {
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    for (hvd_hasher* hs : g_parked) free_hasher(hs);
+    g_parked.clear();
+}
+}  // namespace hvd
+
+extern "C" {
+
+int hvd_hasher_destroy(hvd_hasher* hs) {
+    if (!hs) return HVD_OK;
+    (void)hvd::api_bind_device();
+    bool complete = true;
+    for (Slot& s : hs->slot) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        complete = complete && s.stream && s.done && s.h_frames && s.h_hashes && s.h_quality && s.d_frames && s.d_hashes &&
+                   s.d_quality;
+        s.filled = s.in_flight = 0;
+    }
+    if (complete && hvd::api_dct_device()) {  // park it for the next video (never after hvd_shutdown)
+        hs->hashes.clear();
+        hs->quality.clear();
+        hs->cur = 0;
+        hs->acquired = false;
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        g_parked.push_back(hs);
+        if (g_parked.size() > kMaxParked) {
+            free_hasher(g_parked.front());
+            g_parked.erase(g_parked.begin());
+        }
+        return HVD_OK;
+    }
+    free_hasher(hs);
     return HVD_OK;
 }
 
@@ -109,6 +153,17 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
     if (width < 64 || height < 64 || width > 4096 || height > 4096 || (channels != 1 && channels != 3) || batch_frames < 1)
         return hvd::api_fail(HVD_ERR_ARG, "bad hasher geometry %dx%dx%d batch %lld", width, height, channels,
                              (long long)batch_frames);
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        for (size_t k = g_parked.size(); k-- > 0;) {
+            hvd_hasher* p = g_parked[k];
+            if (p->w == width && p->h == height && p->channels == channels && p->batch == batch_frames) {
+                g_parked.erase(g_parked.begin() + (long)k);
+                *out = p;
+                return HVD_OK;
+            }
+        }
+    }
     hvd_hasher* hs = new hvd_hasher();
     hs->w = width;
     hs->h = height;
@@ -128,7 +183,8 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
         if (e == hipSuccess) e = hipMalloc(&s.d_hashes, 32 * (size_t)batch_frames);
         if (e == hipSuccess) e = hipMalloc(&s.d_quality, 4 * (size_t)batch_frames);
         if (e != hipSuccess) {
-            hvd_hasher_destroy(hs);
+            free_hasher(hs);
+            hvd::stream_release_cache();  // the parked sets may be what exhausted the pinned / device memory
             return hvd::api_fail(HVD_ERR_HIP, "hasher allocation: %s", hipGetErrorString(e));
         }
     }

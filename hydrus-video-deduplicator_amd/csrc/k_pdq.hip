@@ -1290,6 +1290,11 @@ int g_pdq_luma_lut = 1;           // 0: compute luma, 1: LDS table, 2: LDS table
 // 4 % at 10k frames, where every workgroup runs it once or twice; profiles/r02_k1_dct_operand.txt)
 int g_pdq_dct_from_lds = 3;
 
+void pdq_dct_table_copy(float* out_16x64) {
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 64; ++k) memcpy(&out_16x64[i * 64 + k], &kDctBits[i][k], 4);
+}
+
 bool pdq_dct_table_matches(const float* host_16x64) {
     for (int i = 0; i < 16; ++i)
         for (int k = 0; k < 64; ++k) {

@@ -63,8 +63,11 @@ int hvd_init(int device);
 int hvd_shutdown(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf. */
 int hvd_last_error(char* buf, size_t len);
-/* The host-computed DCT matrix the kernels use (16*64 floats), for parity tests. */
+/* The DCT matrix the kernels use (16*64 floats): the table compiled into the library (csrc/dct_table.inc), which is
+ * authoritative -- hashes do not depend on the host's libm. hvd_dct_matrix_libm() recomputes it on this host the way
+ * upstream does (float scale * double cos, rounded once); the parity tests assert the two are bit-identical. */
 int hvd_dct_matrix(float* out_16x64);
+int hvd_dct_matrix_libm(float* out_16x64);
 
 /* ------------------------------------------ host-buffer entry points ------ */
 /* These are what the Python `vpdq`-shaped shim binds; each stages through HBM,
@@ -139,6 +142,10 @@ int hvd_hasher_destroy(hvd_hasher* hs);
 
 int hvd_dev_malloc(void** out_ptr, size_t bytes);
 int hvd_dev_free(void* d_ptr);
+/* Page-locked host memory: hvd_memcpy_h2d/d2h from/to it run at the DMA rate (a decoder that cannot write into
+ * the hasher's slots -- hvd_hasher_acquire -- should at least decode into this); bench.py's H2D probe uses it. */
+int hvd_host_malloc(void** out_ptr, size_t bytes);
+int hvd_host_free(void* h_ptr);
 int hvd_dev_memset(void* d_ptr, int value, size_t bytes);
 int hvd_memcpy_h2d(void* d_dst, const void* src, size_t bytes);
 int hvd_memcpy_d2h(void* dst, const void* d_src, size_t bytes);

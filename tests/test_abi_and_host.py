@@ -66,6 +66,10 @@ def test_dct_matrix_host_copy_matches_oracle(hvd, oracle):
     d = np.zeros((16, 64), np.float32)
     _lib.check(_lib.load().hvd_dct_matrix(d.ctypes.data_as(C.c_void_p)))
     assert np.array_equal(d.view(np.uint32), oracle.dct_matrix().view(np.uint32))
+    # the compiled table is authoritative (hvd_init no longer consults libm); this host's libm must still agree with it
+    m = np.zeros((16, 64), np.float32)
+    _lib.check(_lib.load().hvd_dct_matrix_libm(m.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(d.view(np.uint32), m.view(np.uint32))
 
 
 def test_vpdqhash_value_semantics(hvd):
