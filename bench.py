@@ -41,6 +41,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP4_PEAK_TFLOPS = 10000.0     # dense FP4 MFMA peak (MI355X_MICROARCH.md; measured ceiling 9099)
 BYTES_PER_COMPARISON = 64      # two 32-byte operands, no reuse credited
 BYTES_PER_FRAME_64 = 4096 + 32 + 4
+FLOP_PER_FRAME_64 = 163_840    # the two DCT stages: 2 x 81 920 separately rounded multiplies and adds
+VALU_F32_NOFMA_TFLOPS = 78.6   # fp32 VALU peak without FMA (half of the 157.3 TFLOP/s FMA figure, MI355X_MICROARCH.md)
 BYTES_PER_FRAME_RGB512 = 786432 + 32 + 4
 
 
@@ -91,6 +93,23 @@ def mean_sd(xs):
 
 def sig(x, digits=4):
     return float(f"{x:.{digits}g}")
+
+
+TRAFFIC_SOURCE = ("profiles/hbm_traffic.json: PMC bytes per launch from a separate rocprofv3 --pmc side-run of the same "
+                  "kernels (FETCH_SIZE x2 + WRITE_SIZE, separate passes), not re-measured inside this run")
+
+
+def k1_roofline(fps_per_gpu, traffic):
+    """64x64 hash kernel: bound by the fp32 VALU (the bit-exact DCT is 2 separately rounded ops per MAC, no FMA, no
+    MFMA), so the fraction is executed DCT flop over the non-FMA fp32 peak; the HBM view rides along."""
+    tf = fps_per_gpu * FLOP_PER_FRAME_64 / 1e12
+    gbs = fps_per_gpu * BYTES_PER_FRAME_64 / 1e9
+    return {"bound": "valu", "kernel": "k_pdq_hash64", "achieved": round(tf, 2), "peak": VALU_F32_NOFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / VALU_F32_NOFMA_TFLOPS, 3), "traffic": traffic,
+            "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
+            "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+            "note": "algorithmic flop = 163 840 per frame (the two DCT stages, multiply and add rounded separately); "
+                    "algorithmic bytes = 4 132 per frame; peak = fp32 VALU without FMA"}
 
 
 def load_traffic(key):
@@ -496,13 +515,15 @@ def main():
         roofline = {"bound": "mfma", "kernel": f"k_allpairs_mfma(variant={variant}" + (f" -> form {form} chosen by the probe)" if variant == 13 else ")"),
                     "achieved": round(tfl, 1),
                     "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / FP4_PEAK_TFLOPS, 3),
-                    "traffic": traffic, "kernel_ms": round(kernel_avg_ms, 3), "kernel_ms_sd_rank0": round(k_sd, 3),
+                    "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
+                    "kernel_ms": round(kernel_avg_ms, 3), "kernel_ms_sd_rank0": round(k_sd, 3),
                     "instr": "v_mfma_f32_32x32x64_f8f6f4 cbsz:4 blgp:4 on the +-1 FP4 image of the hashes",
                     "flop_per_comparison_executed": flop_per_cmp, "hbm_equivalent": hbm_equiv,
                     "note": "kernel_ms covers everything between the HIP events of one pass: probe + form selection + the "
                             "all-pairs kernel; `achieved` counts only the first-stage MFMAs every comparison executes"}
     else:
         roofline = {"bound": "hbm", "kernel": f"k_allpairs(variant={variant})", "traffic": traffic,
+                    "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
                     "kernel_ms": round(kernel_avg_ms, 3), **hbm_equiv,
                     "note": hbm_equiv["note"] + "; binding unit: integer VALU (v_bcnt_u32_b32 issues at half rate, "
                                                 "profiles/r01_ubench_valu.txt)"}
@@ -513,12 +534,7 @@ def main():
                     "(BASELINE configs[1]; frames are independent, ranks hash disjoint batches, no collective)",
         "value": sig(fps), "unit": "frames/s", "kernel_ms": round(k1_ms, 4), "kernel_ms_sd": round(k1_sd, 4), "dtype": "f32",
         "n_gpus": world, "wall_value": sig(world * args.frames * 50 / k1_wall),
-        "roofline": {"bound": "hbm", "kernel": "k_pdq_hash64", "achieved": round(fps / world * BYTES_PER_FRAME_64 / 1e9, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(fps / world * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": load_traffic(f"pdq_hash64_n{args.frames}"),
-                     "note": "fp32-VALU-bound at 64x64 (bit-exact non-FMA DCT: 2 VALU ops per MAC; PMC: SIMDs "
-                             "issue-saturated, profiles/r01_pmc_k1.txt), not HBM-bound"},
+        "roofline": k1_roofline(fps / world, load_traffic(f"pdq_hash64_n{args.frames}")),
     }
 
     out = {
@@ -556,9 +572,10 @@ def main():
         dh2.free()
         dq2.free()
         m400, s400 = mean_sd(kl)
-        frames_out["batch_400k"] = {"value": sig(400_000 / (m400 * 1e-3)), "unit": "frames/s", "kernel_ms": round(m400, 3),
-                                    "kernel_ms_sd": round(s400, 3), "traffic": load_traffic("pdq_hash64_n400000"),
-                                    "hbm_frac": round(400_000 / (m400 * 1e-3) * BYTES_PER_FRAME_64 / 1e9 / HBM_PEAK_GBS, 4)}
+        frames_out["batch_400k"] = {"workload": "400 000 frames in one launch: the 10 000 distinct frames of configs[1] x 40 on the device",
+                                    "value": sig(400_000 / (m400 * 1e-3)), "unit": "frames/s", "kernel_ms": round(m400, 3),
+                                    "kernel_ms_sd": round(s400, 3),
+                                    "roofline": k1_roofline(400_000 / (m400 * 1e-3), load_traffic("pdq_hash64_n400000"))}
 
         # the headline DB again for the side-by-side legs
         d_db = L.DeviceBuffer.from_array(db)
@@ -644,13 +661,14 @@ def main():
         rgb_ms, rgb_sd = mean_sd(rl)
         rgb_fps = n_rgb / (rgb_ms * 1e-3)
         frames_out["rgb24_512x512"] = {
-            "workload": f"{n_rgb} pre-decoded synthetic 512x512 RGB24 frames (the reference's hash_frame input): luma + "
-                        "2x Jarosz + decimate (k_down512w, one wave per frame) + k_pdq_hash64",
+            "workload": f"{n_rgb} pre-decoded synthetic 512x512 RGB24 frames (16 distinct frames x {n_rgb // 16} on the device; "
+                        "the reference's hash_frame input): luma + 2x Jarosz + decimate (k_down512w, one wave per frame) + "
+                        "k_pdq_hash64",
             "value": sig(rgb_fps), "unit": "frames/s", "ms": round(rgb_ms, 3), "ms_sd": round(rgb_sd, 3),
             "roofline": {"bound": "hbm", "kernel": "k_down512w", "achieved": round(rgb_fps * BYTES_PER_FRAME_RGB512 / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(rgb_fps * BYTES_PER_FRAME_RGB512 / 1e9 / HBM_PEAK_GBS, 3),
-                         "traffic": load_traffic(f"down512w_rgb_n{n_rgb}"),
+                         "traffic": load_traffic(f"down512w_rgb_n{n_rgb}"), "traffic_source": TRAFFIC_SOURCE,
                          "note": "algorithmic bytes = 786432 in + 36 out per frame; `traffic` = PMC bytes per launch "
                                  "(FETCH_SIZE x2 + WRITE_SIZE, profiles/)"}}
 
@@ -678,21 +696,29 @@ def main():
             from oracle import oracle as O  # cpu_baseline leg only
 
             cores = host_threads()
+            # The baseline build: the oracle recompiled ON this box with -O3 -march=native (falls back to the
+            # portable -O2 -mpopcnt library if there is no compiler), AVX-512 VPOPCNTDQ scan where CPUID offers it.
             # bounded sample of the same workload: calibrate, then ~cpu-seconds of work
+            def cpu_rate(n_, threads, native):
+                t_ = time.perf_counter()
+                O.allpairs_count(db[:n_], 31, num_threads=threads, native=native)
+                return (n_ * (n_ - 1) / 2) / (time.perf_counter() - t_)
+
             n0 = min(n, 150_000)  # big enough that thread start-up does not dominate on many-core hosts
-            O.allpairs_count(db[:n0], 31, num_threads=cores)  # warm: page in, spawn once
-            t = time.perf_counter()
-            O.allpairs_count(db[:n0], 31, num_threads=cores)
-            rate = (n0 * (n0 - 1) / 2) / (time.perf_counter() - t)
+            cpu_rate(n0, cores, True)  # warm: build, page in, spawn once
+            rate = cpu_rate(n0, cores, True)
             ns = int(min(n, max(n0, math.sqrt(2 * rate * args.cpu_seconds))))
             t = time.perf_counter()
-            O.allpairs_count(db[:ns], 31, num_threads=cores)
+            O.allpairs_count(db[:ns], 31, num_threads=cores, native=True)
             dt = time.perf_counter() - t
             cpu_cmp = ns * (ns - 1) / 2 / dt
-            n1 = min(n, 60_000)  # single-thread figure on a small prefix (~1-2 s)
-            t = time.perf_counter()
-            O.allpairs_count(db[:n1], 31, num_threads=1)
-            cpu_cmp_1t = n1 * (n1 - 1) / 2 / (time.perf_counter() - t)
+            n1 = min(n, 60_000)  # single-thread and portable-build figures on smaller prefixes (~1-2 s each)
+            cpu_cmp_1t = cpu_rate(n1, 1, True)
+            cpu_rate(n0, cores, False)
+            cpu_cmp_portable = cpu_rate(n0, cores, False)
+            cpu_flags = {"value_build": O.native_lib().flags, "avx512_vpopcntdq": O.uses_avx512(True),
+                         "portable_build": O.PORTABLE_FLAGS, "portable_value": sig(cpu_cmp_portable),
+                         "portable_avx512_vpopcntdq": O.uses_avx512(False)}
             t = time.perf_counter()
             ho, qo = O.hash_frames(fr, num_threads=cores)
             dtf = time.perf_counter() - t
@@ -724,8 +750,10 @@ def main():
                                   "records": int(len(rec_g)), "cpu_value": sig(k3_cmp / dt_c), "cpu_threads": 1,
                                   "note": "small problem: transfer + launch overheads dominate the GPU figure; config5 above is "
                                           "the same path at full size"}
-            cpu = {"value": sig(cpu_cmp), "unit": "comparisons/s", "cores": cores, "kind": "port",
-                   "sample": f"oracle (C, popcnt, pthreads) all-pairs over the first {ns} of the {n} hashes "
+            cpu = {"value": sig(cpu_cmp), "unit": "comparisons/s", "cores": cores, "kind": "port", "flags": cpu_flags,
+                   "sample": f"oracle (C, pthreads; {cpu_flags['value_build']}; "
+                             f"{'AVX-512 VPOPCNTDQ block scan' if cpu_flags['avx512_vpopcntdq'] else 'scalar popcnt loop'}) "
+                             f"all-pairs over the first {ns} of the {n} hashes "
                              f"({ns * (ns - 1) // 2:.3g} comparisons, {dt:.1f} s)",
                    "value_1thread": sig(cpu_cmp_1t),
                    "speedup_over_1thread": round(cpu_cmp / cpu_cmp_1t, 1), "os_cpu_count": os.cpu_count(),

@@ -122,9 +122,41 @@ def allpairs(db: np.ndarray, max_dist: int = 31, group: np.ndarray | None = None
     return res
 
 
-def allpairs_count(db: np.ndarray, max_dist: int = 31, num_threads: int = 1) -> int:
+def allpairs_count(db: np.ndarray, max_dist: int = 31, num_threads: int = 1, native: bool = False) -> int:
     db = np.ascontiguousarray(db, dtype=np.uint8).reshape(-1, 32)
-    return int(lib().hvd_cpu_allpairs_count(db.ctypes.data, db.shape[0], max_dist, num_threads))
+    L = native_lib() if native else lib()
+    return int(L.hvd_cpu_allpairs_count(db.ctypes.data, db.shape[0], max_dist, num_threads))
+
+
+NATIVE_FLAGS = "-O3 -march=native"
+PORTABLE_FLAGS = "-O2 -mpopcnt"
+_native = None
+
+
+def native_lib():
+    """The oracle rebuilt on THIS host with -O3 -march=native (cpu_baseline leg of bench.py; `make native`), or the
+    portable library when no compiler is available here. Only the all-pairs counter is bound."""
+    global _native
+    if _native is None:
+        so = os.path.join(_HERE, "libhvd_oracle_native.so")
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            L = C.CDLL(so)
+            L.flags = NATIVE_FLAGS
+        except (OSError, subprocess.CalledProcessError):
+            L = C.CDLL(build())
+            L.flags = PORTABLE_FLAGS + " (no compiler on this host: portable build)"
+        L.hvd_cpu_allpairs_count.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.hvd_cpu_allpairs_count.restype = C.c_int64
+        L.hvd_cpu_allpairs_uses_avx512.restype = C.c_int
+        _native = L
+    return _native
+
+
+def uses_avx512(native: bool = False) -> bool:
+    L = native_lib() if native else lib()
+    L.hvd_cpu_allpairs_uses_avx512.restype = C.c_int
+    return bool(L.hvd_cpu_allpairs_uses_avx512())
 
 
 def match_two(a: bytes, b: bytes, max_dist: int = 31) -> tuple[int, int]:

@@ -34,7 +34,7 @@ def hvd():
 
 @pytest.fixture(scope="session")
 def gpu(hvd):
-    """Initialised library on cuda:0 -- fails (not skips) if the HIP extension is unusable."""
+    """Initialised library on HIP device 0 -- fails (not skips) if the HIP extension is unusable."""
     from hvd_amd import _lib
 
     _lib.init(0)

@@ -1,6 +1,8 @@
 """CPU tests of the oracle itself: the C restatement against the independent numpy
 restatement, against the committed golden fixtures, and against analytic known answers.
 (The reference's own vectors are unavailable -- PARITY UNPINNED, oracle/hvd_oracle.c.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -277,3 +279,35 @@ def test_quality_term_gray_shortcut_is_exact():
     # the neighbouring floats do NOT have the property: the constant is not arbitrary
     for other in (np.nextafter(c, f32(0)), np.nextafter(c, f32(1))):
         assert not np.array_equal(np.trunc((np.abs(d) * other).astype(f32)).astype(np.int64), ref)
+
+
+def test_avx512_scan_reports_exactly_what_the_scalar_loop_reports(oracle, tmp_path):
+    """The CPU baseline's AVX-512 VPOPCNTDQ scan (oracle/hvd_oracle.c) only finds candidates faster; every record still
+    comes from the scalar statement. Run the same searches in two processes, one with the vector path forced off."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from oracle import oracle as O\n"
+        "from hvd_amd import synth\n"
+        "db, _ = synth.hash_db_clustered(5003, 50, 20, seed=8)\n"
+        "u, _ = synth.hash_db(20001, seed=3)\n"
+        "grp = (np.arange(5003) // 3).astype(np.int32)\n"
+        "r = [O.allpairs(db, 31), O.allpairs(db, 31, group=grp), O.allpairs(db, 40, rows=(1001, 3007)),\n"
+        "     O.allpairs(u, 31, num_threads=3), O.allpairs(db[:63], 31), O.allpairs(db[:64], 255), O.allpairs(db[:71], 0)]\n"
+        "print(int(O.uses_avx512()), O.allpairs_count(u, 31, 2))\n"
+        "np.save(sys.argv[1], np.concatenate([x.view(np.uint32).ravel() for x in r]))\n" % ROOT)
+    outs = []
+    for k, env_extra in enumerate(({}, {"HVD_ORACLE_NO_AVX512": "1"})):
+        out = tmp_path / f"r{k}.npy"
+        p = subprocess.run([sys.executable, str(script), str(out)], env={**os.environ, **env_extra}, capture_output=True,
+                           check=True)
+        outs.append((p.stdout.split(), np.load(out)))
+    assert outs[1][0][0] == b"0"  # the switch works
+    assert outs[0][0][1] == outs[1][0][1]
+    assert np.array_equal(outs[0][1], outs[1][1]) and outs[0][1].size > 1000
