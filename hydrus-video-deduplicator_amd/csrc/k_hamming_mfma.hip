@@ -124,10 +124,40 @@ __device__ __forceinline__ void append_pair_m(hvd_pair* out, unsigned long long 
     }
 }
 
+// Frame-pair sink, round 3: hits are collected per WORKGROUP in LDS and flushed with ONE global atomic when the
+// workgroup is done. `count` is a single address shared by the whole chip, and device-scope atomics on one address
+// serialise at the memory side (round 2 measured ~8 ns per appended pair on a clustered DB: 41 ms for 4.95 M pairs --
+// the append, not the compare, set the pace). A workgroup walks 8.4 M comparisons; even a heavily clustered DB leaves
+// well under kWgPairs hits per workgroup, and the overflow (one workgroup covering two copies of the same long video in
+// frame-pair mode) falls back to the direct append, so nothing is ever dropped. File-scope LDS so that the noinline hit
+// handler reaches it without another argument register.
+constexpr uint32_t kWgPairs = 512;
+__shared__ hvd_pair g_wg_pairs[kWgPairs];
+__shared__ uint32_t g_wg_npairs;
+
+__device__ __forceinline__ void append_pair_wg(hvd_pair* out, unsigned long long cap, unsigned long long* count,
+                                               uint32_t i, uint32_t j, uint32_t dist) {
+    const uint32_t slot = atomicAdd(&g_wg_npairs, 1u);
+    if (slot < kWgPairs) {
+        hvd_pair p;
+        p.i = i;
+        p.j = j;
+        p.dist = dist;
+        p.pad = 0;
+        g_wg_pairs[slot] = p;
+    } else {
+        append_pair_m(out, cap, count, i, j, dist);
+    }
+}
+
 #ifndef HVD_K2_SIGN
 #define HVD_K2_SIGN 1  // 1: threshold folded into negated accumulators, OR-reduction (or16_bits); 0: plain dot, max-reduction
 #endif
 constexpr bool kSign = HVD_K2_SIGN != 0;
+#ifndef HVD_K2_CASCADE
+#define HVD_K2_CASCADE 1  // 1: survivors of the 128-bit stage go 128 -> 192 -> 256; 0: 128 -> 256 (round 2)
+#endif
+constexpr bool kCascade = HVD_K2_CASCADE != 0;
 
 constexpr int kSuper = 128;  // candidates per LDS super-panel (256: -4 % with the prefilter, +2 % without)
 
@@ -189,6 +219,23 @@ __device__ __forceinline__ HitCtx load_ctx(const HitCtx* ctx) {
 #endif
 }
 
+// End of the workgroup's tile (all waves past their last barrier): reserve room for the collected pairs with one
+// global atomic and copy them out. noinline: nothing of the fast path is live any more when it is called, and kept
+// out of line it does not disturb the register allocation of the loop (inlined it cost the fetch form 6 VGPRs = one
+// resident wave per SIMD).
+// (tid is an argument: a callee that reads threadIdx makes the caller keep the packed work-item ids alive in v31.)
+__device__ __noinline__ void flush_pairs_wg(const HitCtx* __restrict__ ctx, uint32_t tid) {
+    __shared__ unsigned long long base_s;
+    const uint32_t m = min(g_wg_npairs, kWgPairs);
+    if (m == 0u) return;  // uniform over the workgroup
+    const HitCtx c = load_ctx(ctx);
+    if (tid == 0u) base_s = atomicAdd(c.count, (unsigned long long)m);
+    __syncthreads();
+    const unsigned long long base = base_s;
+    for (uint32_t k = tid; k < m; k += 256u)
+        if (base + k < c.cap) c.out[base + k] = g_wg_pairs[k];
+}
+
 // acc holds sgn * dot + off (sgn = +1, off = 0 for a plain recomputation; sgn = -1, off = start value for the fast
 // path's negated accumulators): dot = sgn * (acc - off) ... written as one exact fma on small integers.
 __device__ __forceinline__ void tile_hits_body(const v16f& acc, uint32_t row0, uint32_t j, uint32_t lane, const HitCtx& c,
@@ -217,7 +264,7 @@ __device__ __forceinline__ void tile_hits_body(const v16f& acc, uint32_t row0, u
         bool ok = dot >= c.thr_full && j < c.n && (rect ? i < c.nq : i < j);
         if (ok && c.group != nullptr) ok = c.group[i] != gcol;
         if (!video) {
-            if (ok) append_pair_m(c.out, c.cap, c.count, i, j, (uint32_t)(256 - (int)(dot * c.inv_scale2)) >> 1);
+            if (ok) append_pair_wg(c.out, c.cap, c.count, i, j, (uint32_t)(256 - (int)(dot * c.inv_scale2)) >> 1);
             continue;
         }
         const unsigned long long rowhits = __ballot(ok);
@@ -337,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     const uint32_t lane = tid & 63u, li = lane & 31u, h = lane >> 5;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wrow0 = row0 + wave * WROWS;
+    if (tid == 0u) g_wg_npairs = 0u;  // (ordered before any hit by the barrier behind the first staged super-panel)
 
     // A fragments: query hash (wrow0 + 32t + li), chunk 2s+h, for the whole tile.
     v4i a[TILES][NBR];
@@ -357,6 +405,8 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     // goes on to acc = c1 - dot256, a hit <=> dot256 >= 256 - 2*max_dist <=> acc <= c1 - thr_full = -129*scale2 (S1 = 2)
     const float c1 = kSign ? scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist - 1.0f) : 0.0f;
     const float hit2 = -128.5f * scale2;
+    const float hit192 = -64.5f * scale2;  // after 192 bits: dot192 >= 192 - 2*max_dist <=> acc <= c1 - that = -65*scale2
+    const int thr192_bits = __float_as_int(scale2 * (192.0f - 2.0f * (float)max_dist));
     const int thr1_bits = __float_as_int(scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist));  // plain form
     const int thr2_bits = __float_as_int(scale2 * (256.0f - 2.0f * (float)max_dist));
     // marks' = marks << 1 | verdict(acc): v_alignbit_b32 takes the sign bit of the OR straight into the mask
@@ -366,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
     };
     auto stage1_hit = [&](const v16f& acc) { return kSign ? __any(or16_bits(acc) < 0) : __any(max16_bits(acc) >= thr1_bits); };
     auto stage2_hit = [&](const v16f& acc) { return kSign ? __any(min16(acc) < hit2) : __any(max16_bits(acc) >= thr2_bits); };
+    auto stage192_hit = [&](const v16f& acc) { return kSign ? __any(min16(acc) < hit192) : __any(max16_bits(acc) >= thr192_bits); };
 
     // candidates <= row0 cannot pair with rows >= row0 (i<j): start at the super-panel holding row0+1
     const uint32_t j0 = RECT ? col0 : max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
@@ -408,10 +459,19 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
                 // tile with a real hit (all 256 bits) calls the handler
                 auto survivor = [&](const int t, v16f acc) {
                     if (S1 == 2) {
-                        v4i b2[2];
+                        // cascade 128 -> 192 -> 256 bits (every partial distance bounds the full one from below): on real
+                        // frame hashes 2e-4 of all pairs pass the first 128 bits, i.e. most (wave, panel) steps see a
+                        // false survivor -- it now costs ONE more MFMA, and only what also survives 192 bits a second
+                        if (kCascade) {
+                            acc = mfma_fp4(a[t][2], as_v4i(base[(4u + h) ^ sw]), acc);
+                            if (!stage192_hit(acc)) return;
+                            acc = mfma_fp4(a[t][3], as_v4i(base[(6u + h) ^ sw]), acc);
+                        } else {
+                            v4i b2[2];
 #pragma unroll
-                        for (int s = 0; s < 2; ++s) b2[s] = as_v4i(base[(2u * (s + 2) + h) ^ sw]);
-                        acc = tile_dot<0, 2>(&a[t][2], b2, acc);
+                            for (int s = 0; s < 2; ++s) b2[s] = as_v4i(base[(2u * (s + 2) + h) ^ sw]);
+                            acc = tile_dot<0, 2>(&a[t][2], b2, acc);
+                        }
                         if (!stage2_hit(acc)) return;
                     }
                     tile_hits<kSign>(acc, wrow0 + 32u * (uint32_t)t, jsp + cl, lane, ctx);
@@ -442,6 +502,8 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
         process(lds1, jsp + kSuper);
         __syncthreads();
     }
+    // every path leaves the loop through a barrier: all hits of this workgroup are in LDS now
+    flush_pairs_wg(ctx, wave * 64u + lane);
 }
 
 // Probe for the data-dependent choice of the kernel form: over a strided sample of the two images (up to 4096 rows
