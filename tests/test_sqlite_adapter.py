@@ -30,6 +30,14 @@ class OracleMatcher:
     def match_videos(self, frames, offsets, max_dist):
         return self.o.match_videos(frames, offsets, max_dist)
 
+    def calculate_distance(self, a, b):
+        """db/vptree.py:29-31 with the oracle as matchHashBytes (comparator le, policy min: the repo's defaults)."""
+        na, nb = len(a) // 32, len(b) // 32
+        if na == 0 or nb == 0:
+            return 101
+        q, t = self.o.match_two(bytes(a), bytes(b), 31)
+        return (100 - int(min(q * 100.0 / na, t * 100.0 / nb))) + 1
+
     def match_videos_cross(self, fq, oq, ft, ot, ids_q=None, ids_t=None, max_dist=31):
         from hvd_amd._lib import VMATCH_DTYPE
 
