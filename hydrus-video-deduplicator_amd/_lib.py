@@ -74,6 +74,7 @@ SIGNATURES = {
     "hvd_dev_video_of_frames": (_int, [_vp, _i64, _i64, _vp]),
     "hvd_dev_compact_kept": (_int, [_vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, C.POINTER(_i64)]),
     "hvd_dev_vpdq_match_videos": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _i64, _vp]),
+    "hvd_dev_vpdq_emit_again": (_int, [_vp, _i64, _vp]),
     "hvd_dev_vpdq_match_videos_cross": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _int, _int, _int, _vp, _i64,
                                                _vp]),
     "hvd_dev_synth_video_frames": (_int, [_vp, _i64, _i64, _int, C.c_uint64, _vp]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "hvd_comm_allgather_pairs": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "hvd_comm_allgather_bytes": (_int, [_vp, _vp, _sz]),
     "hvd_comm_destroy": (_int, []),
+    "hvd_comm_abort": (_int, []),
 }
 
 

@@ -78,6 +78,7 @@ struct Ctx {
     size_t scr_cap[S_N] = {};
     unsigned long long v_pslots = 0;  // pair map left behind by vmatch_build for vmatch_emit
     int v_exchange_mode = 0;          // hvd_debug_set("vmatch_exchange"): 0 exchange keys iff world > 1, 1 always, 2 never
+    int v_fail_rank = 0;              // hvd_debug_set("vmatch_fail_rank"): rank + 1 whose local phase fails (tests the agreement step)
     int v_force_slots_log2 = 0;       // hvd_debug_set("vmatch_slots_log2"): start the tables this small (tests the regrowth)
     std::recursive_mutex h_mu;
 };
@@ -372,6 +373,10 @@ int hvd_debug_set(const char* key, int value) {
     if (strcmp(key, "vmatch_slots_log2") == 0) {
         if (value != 0 && (value < 4 || value > 30)) return fail(HVD_ERR_ARG, "vmatch_slots_log2: 0 (automatic) or 4..30");
         g.v_force_slots_log2 = value;
+        return HVD_OK;
+    }
+    if (strcmp(key, "vmatch_fail_rank") == 0) {  // tests: rank (value - 1) fails before the key exchange; 0 = off
+        g.v_fail_rank = value;
         return HVD_OK;
     }
     if (strcmp(key, "vmatch_exchange") == 0) {
@@ -805,13 +810,19 @@ int vmatch_build(const VmArgs& v) {
     const bool exchange = g.v_exchange_mode == 1 || (g.v_exchange_mode == 0 && v.world > 1);
     if (exchange && (!g.comm_ready || g.world != v.world || g.rank != v.rank))
         return fail(HVD_ERR_STATE, "rank %d of %d needs hvd_comm_init() with the same rank/world first", v.rank, v.world);
+    // world > 1: a rank that fails on its own (out of memory while a table regrows, a launch error) must not leave its
+    // peers blocked in the all-gathers below. Everything up to the exchange runs inside `local`, whose result code rides
+    // along with the key count in the first all-gather: every rank learns of a failure anywhere and all of them return.
     unsigned long long* d_counters = nullptr;
-    SCR(S_COUNTERS, 64, d_counters);
-    const unsigned long long frames = (unsigned long long)v.nt + (v.rect ? v.nq : 0u);
-    unsigned long long slots = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * frames));
-    if (g.v_force_slots_log2) slots = 1ull << g.v_force_slots_log2;
+    unsigned long long slots = 0;
     unsigned long long* d_set = nullptr;
     unsigned long long c[4] = {0, 0, 0, 0};
+    auto local = [&]() -> int {
+    SCR(S_COUNTERS, 64, d_counters);
+    const unsigned long long frames = (unsigned long long)v.nt + (v.rect ? v.nq : 0u);
+    slots = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * frames));
+    if (g.v_force_slots_log2) slots = 1ull << g.v_force_slots_log2;
+    if (g.v_fail_rank == v.rank + 1) return fail(HVD_ERR_HIP, "injected failure on rank %d (hvd_debug_set vmatch_fail_rank)", v.rank);
     for (;;) {
         SCR(S_SET, 8 * slots, d_set);
         HIP_TRY(hipMemsetAsync(d_set, 0xFF, 8 * slots, g.stream));
@@ -836,29 +847,49 @@ int vmatch_build(const VmArgs& v) {
         if (c[0] == 0) break;
         slots *= 4;  // some insert ran out of probes: larger table, same pass again
     }
+    return HVD_OK;
+    };
+    const int local_rc = local();
+    if (!exchange && local_rc) return local_rc;
     const unsigned long long* d_src = d_set;
     unsigned long long n_src = slots, n_keys = c[1];
     if (exchange) {
         // each rank saw only its tiles' hits: all-gather the key lists and de-duplicate (a key may be found twice)
         unsigned long long *d_list = nullptr, *d_all = nullptr, *d_set2 = nullptr;
         const int W = g.world;
-        if (!g.x_cnt_in) HIP_TRY(hipMalloc(&g.x_cnt_in, 8));
-        if (!g.x_cnt_all) HIP_TRY(hipMalloc(&g.x_cnt_all, 8 * (size_t)W));
-        HIP_TRY(hipMemcpyAsync(g.x_cnt_in, &n_keys, 8, hipMemcpyHostToDevice, g.stream));
-        NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 1, ncclUint64, g.comm, g.stream));
-        std::vector<unsigned long long> counts((size_t)W);
-        HIP_TRY(hipMemcpyAsync(counts.data(), g.x_cnt_all, 8 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
+        // (the two small exchange words were allocated by hvd_comm_init: nothing can fail between here and the collective)
+        unsigned long long word[2] = {local_rc ? 0ull : n_keys, (unsigned long long)(unsigned)(local_rc ? 1 : 0)};
+        std::vector<unsigned long long> words(2 * (size_t)W);
+        auto agree = [&](const char* what, int own_rc) -> int {  // all-gather (count, status); a failure anywhere -> everyone leaves
+            HIP_TRY(hipMemcpyAsync(g.x_cnt_in, word, 16, hipMemcpyHostToDevice, g.stream));
+            NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 2, ncclUint64, g.comm, g.stream));
+            HIP_TRY(hipMemcpyAsync(words.data(), g.x_cnt_all, 16 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            for (int r = 0; r < W; ++r)
+                if (words[2 * (size_t)r + 1]) {
+                    if (own_rc) return own_rc;  // our own failure: its message is already recorded
+                    return fail(HVD_ERR_RCCL, "video search abandoned: rank %d failed %s", r, what);
+                }
+            return HVD_OK;
+        };
+        if (int rc = agree("before the key exchange", local_rc)) return rc;
         unsigned long long mx = 1, total = 0;
-        for (unsigned long long x : counts) {
-            mx = std::max(mx, x);
-            total += x;
+        for (int r = 0; r < W; ++r) {
+            mx = std::max(mx, words[2 * (size_t)r]);
+            total += words[2 * (size_t)r];
         }
-        SCR(S_LIST, 8 * mx, d_list);  // this rank's keys, padded with empty keys to the longest list
+        // the exchange buffers depend on the gathered counts: allocate, then agree once more before the big all-gather
+        const int alloc_rc = [&]() -> int {
+            SCR(S_LIST, 8 * mx, d_list);  // this rank's keys, padded with empty keys to the longest list
+            SCR(S_LISTALL, 8 * mx * (size_t)W, d_all);
+            return HVD_OK;
+        }();
+        word[0] = 0;
+        word[1] = alloc_rc ? 1ull : 0ull;
+        if (int rc = agree("while allocating the exchange buffers", alloc_rc)) return rc;
         HIP_TRY(hipMemsetAsync(d_list, 0xFF, 8 * mx, g.stream));
         HIP_TRY(hipMemsetAsync(d_counters + 2, 0, 8, g.stream));
         HIP_TRY(hvd::launch_set_to_list(d_set, slots, d_list, mx, d_counters + 2, g.stream));
-        SCR(S_LISTALL, 8 * mx * (size_t)W, d_all);
         NCCL_TRY(ncclAllGather(d_list, d_all, 8 * mx, ncclUint8, g.comm, g.stream));
         unsigned long long slots2 = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * total));
         if (g.v_force_slots_log2) slots2 = 1ull << g.v_force_slots_log2;
@@ -1101,6 +1132,16 @@ int hvd_dev_vpdq_match_videos(const void* d_img, int64_t n, const void* d_video,
     return HVD_OK;
 }
 
+int hvd_dev_vpdq_emit_again(void* d_out, int64_t cap, void* d_count) {
+    if (int rc = need_ready()) return rc;
+    if (cap < 0 || !d_count || (cap > 0 && !d_out)) return fail(HVD_ERR_ARG, "bad output buffer");
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+    if (g.v_pslots == 0 || !g.scr[Ctx::S_PKEYS]) return fail(HVD_ERR_STATE, "no video search to emit from: call hvd_dev_vpdq_match_videos[_cross] first");
+    if (int rc = vmatch_emit((hvd_vmatch*)d_out, cap, (unsigned long long*)d_count)) return rc;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return HVD_OK;
+}
+
 int hvd_dev_vpdq_match_videos_cross(const void* d_img_q, int64_t nq, const void* d_video_q, const void* d_excl_q,
                                     const void* d_img_t, int64_t nt, const void* d_video_t, const void* d_excl_t,
                                     int max_dist, int rank, int world, void* d_out, int64_t cap, void* d_count) {
@@ -1156,6 +1197,10 @@ int hvd_comm_init(const uint8_t id_bytes[HVD_UNIQUE_ID_BYTES], int rank, int wor
     if (g.comm_ready) return fail(HVD_ERR_STATE, "communicator already initialised");
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
+    // the two small words of the video search's agreement step are allocated here, so that nothing can fail between a
+    // rank's decision to enter that collective and the collective itself
+    if (!g.x_cnt_in) HIP_TRY(hipMalloc(&g.x_cnt_in, 16));
+    if (!g.x_cnt_all) HIP_TRY(hipMalloc(&g.x_cnt_all, 16 * (size_t)world));
     NCCL_TRY(ncclCommInitRank(&g.comm, world, id, rank));
     g.comm_ready = true;
     g.rank = rank;
@@ -1182,6 +1227,16 @@ int hvd_comm_destroy(void) {
         NCCL_TRY(ncclCommDestroy(g.comm));
         g.comm_ready = false;
     }
+    return HVD_OK;
+}
+
+int hvd_comm_abort(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready || !g.comm_ready) return HVD_OK;
+    if (int rc = need_ready()) return rc;
+    g.comm_ready = false;  // whatever ncclCommAbort says, nothing may use this communicator again
+    free_exchange_buffers();
+    NCCL_TRY(ncclCommAbort(g.comm));
     return HVD_OK;
 }
 

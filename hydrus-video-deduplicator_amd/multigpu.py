@@ -97,6 +97,10 @@ class RcclExchange:
     def close(self) -> None:
         _lib.check(_lib.load().hvd_comm_destroy())
 
+    def abort(self) -> None:
+        """Drop a communicator that not every rank managed to join (no collective handshake)."""
+        _lib.check(_lib.load().hvd_comm_abort())
+
 
 class HostExchange:
     """The same all-gather of candidate pairs over the control channel (hvd_amd.rendezvous, plain TCP on the
@@ -136,6 +140,13 @@ def connect_rccl(rdzv, timeout: float = 120.0):
     if rdzv.allreduce_min([ok])[0] >= 1.0:
         return box["ex"], "rccl", False
     why = "timed out" if th.is_alive() else repr(box.get("err", "failed on another rank"))
+    if "ex" in box and not th.is_alive():
+        # this rank did join, another did not: the half-formed communicator must not survive -- a later
+        # hvd_comm_destroy / hvd_shutdown on it can hang, and a world > 1 video search would run collectives on it
+        try:
+            box["ex"].abort()
+        except Exception as exc:  # noqa: BLE001 - the fallback path must go on
+            why += f" (abort: {exc!r})"
     return None, why, th.is_alive()
 
 

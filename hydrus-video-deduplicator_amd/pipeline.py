@@ -152,20 +152,22 @@ class DeviceLibrary:
             return np.zeros(0, dtype=VMATCH_DTYPE)
         cap = max(4096, self.n_videos) if cap is None else int(cap)
         d_cnt = DeviceBuffer(8)
+        d_out = DeviceBuffer(16 * cap)
         try:
-            while True:
+            _lib.check(lib.hvd_dev_vpdq_match_videos(self.image().ptr, self.n_frames, self.d_video.ptr, max_dist,
+                                                     rank, world, d_out.ptr, cap, d_cnt.ptr))
+            cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+            if cnt > cap:  # more video pairs than room: ONLY the emit is repeated (no second O(n^2) pass, no second
+                cap = cnt  # key exchange that every rank would have to enter in lock-step)
+                d_out.free()
                 d_out = DeviceBuffer(16 * cap)
-                try:
-                    _lib.check(lib.hvd_dev_vpdq_match_videos(self.image().ptr, self.n_frames, self.d_video.ptr, max_dist,
-                                                             rank, world, d_out.ptr, cap, d_cnt.ptr))
-                    cnt = int(d_cnt.to_array(np.uint64, 1)[0])
-                    if cnt <= cap:
-                        recs = d_out.to_array(VMATCH_DTYPE, cnt)
-                        return recs[np.lexsort((recs["b"], recs["a"]))]
-                    cap = cnt
-                finally:
-                    d_out.free()
+                _lib.check(lib.hvd_dev_vpdq_emit_again(d_out.ptr, cap, d_cnt.ptr))
+                cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+                assert cnt <= cap
+            recs = d_out.to_array(VMATCH_DTYPE, cnt)
+            return recs[np.lexsort((recs["b"], recs["a"]))]
         finally:
+            d_out.free()
             d_cnt.free()
 
     def free(self) -> None:

@@ -236,6 +236,11 @@ int hvd_dev_compact_kept(const void* d_hashes, const void* d_quality, int64_t n,
  * [0,127]. */
 int hvd_dev_vpdq_match_videos(const void* d_img, int64_t n, const void* d_video, int max_dist, int rank, int world,
                               void* d_out, int64_t cap, void* d_count);
+/* The records of the LAST hvd_dev_vpdq_match_videos[_cross] call once more, into a (larger) buffer: only the emit
+ * step runs -- no compare, no exchange, so in a multi-rank pass a rank whose buffer was too small does not drag the
+ * others into another collective. The pair map of that call stays valid until the next video search on this
+ * process (the host-buffer entry points hvd_vpdq_match_videos[_cross] included). */
+int hvd_dev_vpdq_emit_again(void* d_out, int64_t cap, void* d_count);
 /* Query library x target library form (VpTreeManager.search_file for a batch, db/vptree.py:865-902).
  * d_excl_q / d_excl_t (both or neither): int32 per frame, frames with equal values are not compared. */
 int hvd_dev_vpdq_match_videos_cross(const void* d_img_q, int64_t nq, const void* d_video_q, const void* d_excl_q,
@@ -270,6 +275,10 @@ int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_h
 /* RCCL all-gather of equally sized device buffers (hash shards produced on-device). */
 int hvd_comm_allgather_bytes(const void* d_send, void* d_recv, size_t bytes_per_rank);
 int hvd_comm_destroy(void);
+/* Tear the communicator down WITHOUT the collective handshake of ncclCommDestroy: for a rank whose own
+ * hvd_comm_init succeeded while another rank's failed or timed out (hvd_amd.multigpu.connect_rccl) -- the
+ * half-formed communicator must neither be used nor destroyed normally. Idempotent. */
+int hvd_comm_abort(void);
 
 #ifdef __cplusplus
 }
