@@ -1380,7 +1380,11 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
                              int32_t* d_quality, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int64_t groups = (n + kWaves - 1) / kWaves;
-    const int64_t max_grid = 256 * 7;  // 7 workgroups/CU fit by LDS (21.8 KB each)
+    // 93-100 VGPRs = 4 (5 for the literal form) waves per SIMD: below 64 k frames the grid is what is resident at once,
+    // 4 workgroups per CU, so that no second dispatch round of a few workgroups trails the launch (round 3, 10 k frames:
+    // 1024 workgroups 51-52 us, 1792 54-55 us, profiles/r03_k1_grid.txt); long launches keep 7 per CU (LDS limit), where
+    // workgroups that retire early make room for the rest.
+    const int64_t max_grid = n < 65536 ? 256 * 4 : 256 * 7;
     dim3 grid((unsigned)(groups < max_grid ? groups : max_grid));
     if (g_pdq_hash_grid > 0) grid.x = (unsigned)(groups < g_pdq_hash_grid ? groups : g_pdq_hash_grid);
     if (g_pdq_dct_mode == 1) {
@@ -1390,7 +1394,8 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
             hipLaunchKernelGGL(k_pdq_hash64_fma<1>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
         return hipGetLastError();
     }
-    const int dlds = g_pdq_dct_from_lds == 3 ? (n >= 65536 ? 2 : 0) : g_pdq_dct_from_lds;
+    // literals from 8 k frames on (round 3: with the leaner quality term the literal form also wins at 10 k frames)
+    const int dlds = g_pdq_dct_from_lds == 3 ? (n >= 8192 ? 2 : 0) : g_pdq_dct_from_lds;
     const int lut = g_pdq_luma_lut;
 #define HVD_K1(KIND, D, L) hipLaunchKernelGGL((k_pdq_hash64<KIND, D, L>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality)
     if (kind == 0) {

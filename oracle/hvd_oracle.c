@@ -449,29 +449,51 @@ static inline void compare_and_emit(pair_job* jb, int64_t i, int64_t j, uint64_t
     }
 }
 
+static int pair_cmp(const void* x, const void* y) {
+    const hvd_pair* a = (const hvd_pair*)x;
+    const hvd_pair* b = (const hvd_pair*)y;
+    if (a->i != b->i) return a->i < b->i ? -1 : 1;
+    return a->j < b->j ? -1 : (a->j > b->j ? 1 : 0);
+}
+
 static void* pair_worker(void* arg) {
     pair_job* jb = (pair_job*)arg;
     const uint64_t* d = (const uint64_t*)jb->db; /* db is 8-byte aligned by contract of the callers */
     jb->count = 0;
+#if defined(__x86_64__)
+    if (jb->tdb) {
+        /* Cache-blocked: the candidates are walked in chunks of kChunk hashes (256 KiB of the transposed copy: stays
+         * in L2) and every query row of this thread meets a chunk before the next chunk is touched -- one pass over
+         * the DB per THREAD instead of one per query row (at 1 M hashes the row-at-a-time scan streamed 32 MB per row
+         * and ran at memory speed). Records come out chunk by chunk and are sorted by (i, j) afterwards. */
+        enum { kChunk = 8192 };
+        const int64_t nblk = jb->n / 8;
+        for (int64_t c0 = 0; c0 < jb->n; c0 += kChunk) {
+            const int64_t c1 = c0 + kChunk < jb->n ? c0 + kChunk : jb->n;
+            for (int64_t i = jb->row_begin; i < jb->row_end && i + 1 < c1; ++i) {
+                uint64_t a0 = d[4 * i], a1 = d[4 * i + 1], a2 = d[4 * i + 2], a3 = d[4 * i + 3];
+                int64_t j = i + 1 > c0 ? i + 1 : c0;
+                for (; j < c1 && (j & 7); ++j) compare_and_emit(jb, i, j, a0, a1, a2, a3); /* up to a block boundary */
+                int64_t blk = j / 8;
+                const int64_t blk_end = c1 / 8 < nblk ? c1 / 8 : nblk; /* full blocks inside this chunk */
+                while (blk < blk_end) {
+                    unsigned mask = 0;
+                    blk = scan_blocks_avx512(jb->tdb, blk, blk_end, &d[4 * i], jb->max_dist, &mask);
+                    if (blk >= blk_end) break;
+                    for (; mask; mask &= mask - 1) compare_and_emit(jb, i, blk * 8 + __builtin_ctz(mask), a0, a1, a2, a3);
+                    ++blk;
+                }
+                if (j < blk_end * 8) j = blk_end * 8;
+                for (; j < c1; ++j) compare_and_emit(jb, i, j, a0, a1, a2, a3); /* the chunk's tail below a full block */
+            }
+        }
+        if (jb->count > 1) qsort(jb->out, (size_t)(jb->count < jb->cap ? jb->count : jb->cap), sizeof(hvd_pair), pair_cmp);
+        return NULL;
+    }
+#endif
     for (int64_t i = jb->row_begin; i < jb->row_end; ++i) {
         uint64_t a0 = d[4 * i], a1 = d[4 * i + 1], a2 = d[4 * i + 2], a3 = d[4 * i + 3];
-        int64_t j = i + 1;
-#if defined(__x86_64__)
-        if (jb->tdb) {
-            const int64_t nblk = jb->n / 8;
-            for (; j < jb->n && (j & 7); ++j) compare_and_emit(jb, i, j, a0, a1, a2, a3); /* up to a block boundary */
-            int64_t blk = j / 8;
-            while (blk < nblk) {
-                unsigned mask = 0;
-                blk = scan_blocks_avx512(jb->tdb, blk, nblk, &d[4 * i], jb->max_dist, &mask);
-                if (blk >= nblk) break;
-                for (; mask; mask &= mask - 1) compare_and_emit(jb, i, blk * 8 + __builtin_ctz(mask), a0, a1, a2, a3);
-                ++blk;
-            }
-            if (j < nblk * 8) j = nblk * 8; /* the tail below a full block */
-        }
-#endif
-        for (; j < jb->n; ++j) compare_and_emit(jb, i, j, a0, a1, a2, a3);
+        for (int64_t j = i + 1; j < jb->n; ++j) compare_and_emit(jb, i, j, a0, a1, a2, a3);
     }
     return NULL;
 }
