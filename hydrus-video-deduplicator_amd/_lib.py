@@ -45,6 +45,7 @@ SIGNATURES = {
                                            C.POINTER(_i64)]),
     "hvd_hasher_create": (_int, [_int, _int, _int, _i64, C.POINTER(_vp)]),
     "hvd_hasher_push": (_int, [_vp, _vp]),
+    "hvd_hasher_set_threads": (_int, [_vp, _int]),
     "hvd_hasher_acquire": (_int, [_vp, C.POINTER(_vp)]),
     "hvd_hasher_commit": (_int, [_vp]),
     "hvd_hasher_pending": (_int, [_vp, C.POINTER(_i64)]),

@@ -8,8 +8,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "hvd_kernels.h"
@@ -43,7 +46,113 @@ struct Slot {
 
 }  // namespace
 
+// hash_frame(bytes) is a host memcpy of one frame into the pinned ring; at 512x512 RGB24 one thread moves ~20 GB/s, a
+// third of what the PCIe link behind it takes (bench leg videohasher_stream). The reference's VideoHasher owns
+// `num_threads` worker threads (vpdqpy/vpdqpy.py:113); here they are what splits that copy: a process-wide pool of
+// helper threads, each copying one slice of the frame while the caller copies the first. Helpers spin for a few tens of
+// microseconds after a job (frames arrive back to back) and then sleep on a condition variable, so an idle hasher costs
+// nothing. Small frames (64x64) are copied by the caller alone.
+namespace {
+class CopyPool {
+  public:
+    static constexpr int kMaxHelpers = 7;
+    static constexpr size_t kMinBytesPerThread = 96 << 10;
+
+    ~CopyPool() { stop(); }
+
+    // copy n bytes with up to `threads` threads in total (the caller included)
+    void copy(uint8_t* dst, const uint8_t* src, size_t n, int threads) {
+        int parts = (int)std::min<size_t>((size_t)std::max(1, threads), n / kMinBytesPerThread);
+        if (parts <= 1) {
+            memcpy(dst, src, n);
+            return;
+        }
+        std::lock_guard<std::mutex> job_lk(job_mu_);  // one job at a time (two hashers on two threads take turns)
+        ensure_helpers(parts - 1);
+        parts = std::min(parts, (int)th_.size() + 1);
+        const size_t slice = (n / (size_t)parts + 63) & ~(size_t)63;
+        src_ = src;
+        dst_ = dst;
+        n_ = n;
+        slice_ = slice;
+        parts_ = parts;
+        pending_.store(parts - 1, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        if (sleepers_.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> lk(mu_);
+            cv_.notify_all();
+        }
+        memcpy(dst, src, std::min(slice, n));
+        while (pending_.load(std::memory_order_acquire) > 0) cpu_relax();
+    }
+
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            cv_.notify_all();
+        }
+        gen_.fetch_add(1, std::memory_order_release);
+        for (std::thread& t : th_)
+            if (t.joinable()) t.join();
+        th_.clear();
+        stop_ = false;
+    }
+
+  private:
+    static void cpu_relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    void ensure_helpers(int want) {
+        want = std::min(want, kMaxHelpers);
+        while ((int)th_.size() < want) {
+            const int id = (int)th_.size() + 1;  // slice index of this helper
+            const uint64_t start_gen = gen_.load(std::memory_order_acquire);
+            th_.emplace_back([this, id, start_gen] { run(id, start_gen); });
+        }
+    }
+    void run(int id, uint64_t seen) {
+        for (;;) {
+            int spins = 0;
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                if (++spins < 20000) {
+                    cpu_relax();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lk(mu_);
+                sleepers_.fetch_add(1, std::memory_order_release);
+                cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_release);
+                spins = 0;
+            }
+            if (stop_) return;
+            seen = gen_.load(std::memory_order_acquire);
+            if (id < parts_) {
+                const size_t off = slice_ * (size_t)id;
+                if (off < n_) memcpy(dst_ + off, src_ + off, std::min(slice_, n_ - off));
+                pending_.fetch_sub(1, std::memory_order_release);
+            }
+        }
+    }
+
+    std::vector<std::thread> th_;
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> pending_{0}, sleepers_{0};
+    std::atomic<bool> stop_{false};
+    const uint8_t* src_ = nullptr;
+    uint8_t* dst_ = nullptr;
+    size_t n_ = 0, slice_ = 0;
+    int parts_ = 0;
+};
+CopyPool g_copy_pool;
+}  // namespace
+
 struct hvd_hasher {
+    int copy_threads = 4;  // threads that share one frame's copy into the ring (hvd_hasher_set_threads)
     int w = 0, h = 0, channels = 0;
     int64_t batch = 0;
     size_t frame_bytes = 0;
@@ -111,6 +220,7 @@ void free_hasher(hvd_hasher* hs) {
 
 namespace hvd {
 void stream_release_cache() {
+    g_copy_pool.stop();
     std::lock_guard<std::mutex> lk(g_park_mu);
     for (hvd_hasher* hs : g_parked) free_hasher(hs);
     g_parked.clear();
@@ -159,6 +269,7 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
             hvd_hasher* p = g_parked[k];
             if (p->w == width && p->h == height && p->channels == channels && p->batch == batch_frames) {
                 g_parked.erase(g_parked.begin() + (long)k);
+                p->copy_threads = 4;
                 *out = p;
                 return HVD_OK;
             }
@@ -227,8 +338,16 @@ int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame) {
     if (!hs || !frame) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/frame");
     uint8_t* dst = nullptr;
     if (int rc = hvd_hasher_acquire(hs, &dst)) return rc;
-    memcpy(dst, frame, hs->frame_bytes);
+    g_copy_pool.copy(dst, frame, hs->frame_bytes, hs->copy_threads);
     return hvd_hasher_commit(hs);
+}
+
+/* Threads that share the host-side copy of one frame in hvd_hasher_push (the caller included): the counterpart of the
+ * reference hasher's worker threads. n <= 0: the library default (4). Frames below ~200 KB are copied by the caller. */
+int hvd_hasher_set_threads(hvd_hasher* hs, int n) {
+    if (!hs) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher");
+    hs->copy_threads = n <= 0 ? 4 : std::min(n, 1 + CopyPool::kMaxHelpers);
+    return HVD_OK;
 }
 
 /* Flushes the partial batch, waits for everything, returns all hashes / qualities in push

@@ -147,7 +147,8 @@ class VideoHasher:
     kernels. ``hash_frame`` blocks only when every slot is still in flight, which bounds the
     staging memory like the reference's blocking frame queue (vpdqpy/vpdqpy.py:115-117). The
     reference's hasher runs a CPU thread pool instead; ``num_threads`` is accepted for signature
-    compatibility and ignored. One hasher per decoder thread."""
+    compatibility; what it controls here is how many host threads share the copy of one frame into the ring
+    (0 = library default). One hasher per decoder thread."""
 
     def __init__(self, average_fps: int, width: int, height: int, num_threads: int = 0,
                  batch_bytes: int = 64 << 20):
@@ -172,6 +173,12 @@ class VideoHasher:
         _lib.check(self._lib.hvd_hasher_create(self.width, self.height, channels, batch, C.byref(h)))
         self._handle = h
         self._channels = channels
+        # num_threads: the reference hasher's worker threads (vpdqpy/vpdqpy.py:113; 0 = library default, negative =
+        # "all but n cores", entrypoint.py:79-82) -> the threads that share the host-side copy of a frame into the ring
+        nt = int(self.num_threads) if isinstance(self.num_threads, int) else 0
+        if nt < 0:
+            nt = max(1, (os.cpu_count() or 1) + nt)
+        _lib.check(self._lib.hvd_hasher_set_threads(h, nt))
 
     def acquire_frame(self, channels: int = 3) -> np.ndarray:
         """Zero-copy feed (hvd_hasher_acquire): a writable uint8 view of the pinned slot memory for the NEXT
