@@ -358,7 +358,8 @@ __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src,
 // RECT = false: img_q == img (one set, strict upper triangle). RECT = true: rows come from the
 // query image img_q (nq hashes), candidates from the target image img (n hashes), full rectangle.
 template <int TILES, int NBR, int S1, bool RECT>
-__global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
+// (the 4-tile register form is held to 3 waves per SIMD = 168 VGPRs: with the pre-read fragment it would take 170)
+__global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
                                                           uint32_t max_dist, uint32_t col_chunk, uint32_t rank,
                                                           uint32_t world, const uint4* __restrict__ img_q, float scale2,
                                                           const HitCtx* __restrict__ ctx,
@@ -438,6 +439,11 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
             v4i b[S1];
 #pragma unroll
             for (int s = 0; s < S1; ++s) b[s] = as_v4i(base[(2u * s + h) ^ sw]);
+            // register cascade form: the 192-bit step's B fragment is read WITH the panel's first two, so that a first-stage
+            // survivor goes straight to its MFMA instead of waiting out an LDS round trip first (on frame hashes most
+            // panels have one; same-box A/B on structured hashes: -2.5 %)
+            v4i b192 = b[0];
+            if constexpr (NBR == 4 && S1 == 2 && kCascade) b192 = as_v4i(base[(4u + h) ^ sw]);
 
             // two accumulator sets: the MFMAs of tile t+1 are issued before the max tree of tile t
             if constexpr (NBR == 2) {
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void k_allpairs_mfma(const uint4* __restric
                         // frame hashes 2e-4 of all pairs pass the first 128 bits, i.e. most (wave, panel) steps see a
                         // false survivor -- it now costs ONE more MFMA, and only what also survives 192 bits a second
                         if (kCascade) {
-                            acc = mfma_fp4(a[t][2], as_v4i(base[(4u + h) ^ sw]), acc);
+                            acc = mfma_fp4(a[t][2], b192, acc);
                             if (!stage192_hit(acc)) return;
                             acc = mfma_fp4(a[t][3], as_v4i(base[(6u + h) ^ sw]), acc);
                         } else {
