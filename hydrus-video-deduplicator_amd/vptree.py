@@ -257,10 +257,16 @@ class VpTreeManager:
         if len(self._blobs[pos]) and 1 <= radius:
             out.append((pos, 1))
         lo, hi = int(self._n_off[pos]), int(self._n_off[pos + 1])
+        near = {}
         if hi > lo:
             for other, d in zip(self._n_dst[lo:hi].tolist(), self._n_dist[lo:hi].tolist()):
                 if d <= radius:
                     out.append((other, d))
+                    near[other] = d
+        if radius >= 101:  # threshold 0: "similarity below 1 %" = distance 101 is within the radius too, i.e. EVERY hash
+            out.extend((other, 101) for other in range(len(self._blobs)) if other != pos and other not in near)
+            if not len(self._blobs[pos]):
+                out.append((pos, 101))  # an empty hash matches nothing, itself included (db/DedupeDB.py:555-557)
         return out
 
     # ---- phash <-> files, from one in-memory copy of shape_perceptual_hash_map ------------------------------------------

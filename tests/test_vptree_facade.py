@@ -422,3 +422,19 @@ def test_facade_host_side_scales_to_100k_files(hvd):
     assert (n + 1, 1) in tree.search_file(1, 51)
     conn.execute("DELETE FROM shape_perceptual_hash_map WHERE hash_id = ?", (n + 1,))
     assert (n + 1, 1) not in tree.search_file(1, 51)
+
+
+def test_radius_101_returns_every_file_like_a_tree_that_prunes_nothing(hvd, oracle):
+    """threshold 0 -> search distance 101 = "similarity below 1 %": every hash is within it, empty ones included; the
+    facade stores records only for pairs with a frame hit, so this degenerate radius is completed from the library."""
+    m = OracleMatcher(oracle)
+    conn, blobs = build_db(hvd, n_videos=20)
+    tree = hvd.vptree.VpTreeManager(conn, matcher=m)
+    for h in (1, 4, 12):
+        got = dict(tree.search_file(h, 101)[1:])
+        want = {}
+        for o in range(1, 21):
+            d = m.calculate_distance(blobs[h - 1], blobs[o - 1])
+            want[o] = min(d, want.get(o, 999))
+        assert got == want
+    assert len(tree.search_file(1, 100)) < 21
