@@ -39,7 +39,7 @@ extern "C" {
 
 #define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
 #define HVD_UNIQUE_ID_BYTES 128
-#define HVD_ABI_VERSION 2
+#define HVD_ABI_VERSION 3 /* 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
 /* All-pairs kernel the host entry points use: FP4-MFMA with a 128-bit first stage; which of its two forms runs
  * (survivors fetch their other half | second stage out of registers) is chosen per launch from a probe of the data. */
 #define HVD_DEFAULT_VARIANT 13
