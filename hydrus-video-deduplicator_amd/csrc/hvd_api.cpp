@@ -394,16 +394,19 @@ int hvd_debug_set(const char* key, int value) {
 int hvd_debug_get(const char* key, int* out_value) {
     if (int rc = need_ready()) return rc;
     if (!key || !out_value) return fail(HVD_ERR_ARG, "NULL argument");
-    const bool want_form = strcmp(key, "mfma_auto_form") == 0;
-    if (want_form || strcmp(key, "mfma_probe_survivors") == 0) {
-        uint32_t* sel = nullptr;
-        HIP_TRY(hvd::mfma_select_buffer(&sel));
-        uint32_t v[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(v, sel, 8, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        *out_value = (int)v[want_form ? 0 : 1];
-        return HVD_OK;
-    }
+    // what the probe of the last auto-variant launch saw and chose: form id, survivors over bits 0..127 / 128..255,
+    // 1 if the first stage ran on bits 128..255
+    const char* keys[4] = {"mfma_auto_form", "mfma_probe_survivors", "mfma_probe_survivors_hi", "mfma_auto_half"};
+    for (int k = 0; k < 4; ++k)
+        if (strcmp(key, keys[k]) == 0) {
+            uint32_t* sel = nullptr;
+            HIP_TRY(hvd::mfma_select_buffer(&sel));
+            uint32_t v[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(v, sel, 16, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            *out_value = (int)v[k];
+            return HVD_OK;
+        }
     return fail(HVD_ERR_ARG, "unknown debug key %s", key);
 }
 

@@ -372,6 +372,10 @@ __global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) v
     // data-dependent choice between two forms of this kernel (launch_allpairs_auto): both are launched, the
     // probe's verdict lets one of them run
     if (select != nullptr && *select != select_id) return;
+    // Which 128 bits the first stage sees is the probe's choice too (select[3]): the image keeps bits 0..127 in chunks
+    // 0..3 and bits 128..255 in chunks 4..7, so "the other half first" is chunk ^ 4 in every fragment address -- a
+    // launch-uniform XOR into the slot swizzle. The full-distance paths sum over all eight chunks and do not care.
+    const uint32_t selx = select != nullptr ? (select[3] & 1u) << 2 : 0u;
 
     const uint32_t rb = blockIdx.x, cb = blockIdx.y;
     const uint32_t row0 = rb * ROWS;
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) v
         const uint32_t hash = wrow0 + 32u * t + li;  // < n_pad by construction
 #pragma unroll
         for (int s = 0; s < NBR; ++s) {
-            const uint4 q = imgq[(size_t)hash * 8u + img_slot(hash, 2u * s + h)];
+            const uint4 q = imgq[(size_t)hash * 8u + (img_slot(hash, 2u * s + h) ^ selx)];
             // negated: flip the sign bit of every e2m1 nibble (see or16_bits)
             const uint32_t fl = kSign ? 0x88888888u : 0u;
             a[t][s] = v4i{(int)(q.x ^ fl), (int)(q.y ^ fl), (int)(q.z ^ fl), (int)(q.w ^ fl)};
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) v
         for (uint32_t p = 0; p < kSuper / 32; ++p) {
             const uint32_t cl = 32u * p + li;  // candidate index inside the super-panel
             const uint4* base = &panel[cl * 8u];
-            const uint32_t sw = (cl >> 1) & 7u;  // jsp is a multiple of 128: same swizzle as the global index
+            const uint32_t sw = ((cl >> 1) & 7u) ^ selx;  // jsp is a multiple of 128: same swizzle as the global index
             v4i b[S1];
 #pragma unroll
             for (int s = 0; s < S1; ++s) b[s] = as_v4i(base[(2u * s + h) ^ sw]);
@@ -526,30 +530,39 @@ __device__ __forceinline__ uint32_t sign_diff(const uint4& x, const uint4& y) {
 __global__ __launch_bounds__(256) void k_prefilter_probe(const uint4* __restrict__ img_q, uint32_t nq,
                                                          const uint4* __restrict__ img_t, uint32_t nt, uint32_t max_dist,
                                                          uint32_t* __restrict__ select) {
-    __shared__ uint4 cols[256][4];
+    __shared__ uint4 cols[256][8];
     const uint32_t rows = min(nq, kProbeRows), ncols = min(nt, kProbeCols);
     const uint32_t rstride = nq / rows, cstride = nt / ncols;
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     const uint32_t ri = min(r, rows - 1u) * rstride;
-    uint4 q[4];
+    uint4 q[8];
 #pragma unroll
-    for (uint32_t c = 0; c < 4; ++c) q[c] = img_q[(size_t)ri * 8u + img_slot(ri, c)];
+    for (uint32_t c = 0; c < 8; ++c) q[c] = img_q[(size_t)ri * 8u + img_slot(ri, c)];
     // columns sit half a stride off the rows so that, in the symmetric form, a sample row never meets itself
     const uint32_t c = blockIdx.y * 256u + threadIdx.x;
     const uint32_t ci = min(min(c, ncols - 1u) * cstride + cstride / 2u, nt - 1u);
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) cols[threadIdx.x][k] = img_t[(size_t)ci * 8u + img_slot(ci, k)];
+    for (uint32_t k = 0; k < 8; ++k) cols[threadIdx.x][k] = img_t[(size_t)ci * 8u + img_slot(ci, k)];
     __syncthreads();
     const uint32_t m = blockIdx.y * 256u >= ncols ? 0u : min(256u, ncols - blockIdx.y * 256u);
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, cnt_hi = 0;  // survivors of a first stage over bits 0..127 / over bits 128..255
     for (uint32_t k = 0; k < m; ++k) {
         const uint32_t d = sign_diff(q[0], cols[k][0]) + sign_diff(q[1], cols[k][1]) + sign_diff(q[2], cols[k][2]) +
                            sign_diff(q[3], cols[k][3]);
+        const uint32_t d_hi = sign_diff(q[4], cols[k][4]) + sign_diff(q[5], cols[k][5]) + sign_diff(q[6], cols[k][6]) +
+                              sign_diff(q[7], cols[k][7]);
         cnt += d <= max_dist ? 1u : 0u;
+        cnt_hi += d_hi <= max_dist ? 1u : 0u;
     }
-    if (r >= rows) cnt = 0;
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-    if ((threadIdx.x & 63u) == 0u && cnt) atomicAdd(&select[1], cnt);
+    if (r >= rows) cnt = cnt_hi = 0;
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off);
+        cnt_hi += __shfl_down(cnt_hi, off);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        if (cnt) atomicAdd(&select[1], cnt);
+        if (cnt_hi) atomicAdd(&select[2], cnt_hi);
+    }
 }
 
 // The hit handler's launch-uniform arguments live in device memory (written by this one-lane kernel in stream order
@@ -561,7 +574,12 @@ __global__ void k_set_hit_ctx(HitCtx* __restrict__ dst, const HitCtx src) { *dst
 // register form (id_often) a flat ~5 %: switch when more than ~1 % of the (wave, panel) steps would see a survivor.
 __global__ void k_probe_decide(uint32_t* __restrict__ select, uint64_t pairs, uint32_t pairs_per_step, uint32_t id_rare,
                                uint32_t id_often) {
-    const double rate = pairs ? (double)select[1] / (double)pairs : 0.0;
+    // first the half: the one whose 128 bits let fewer unrelated pairs through (ties and near-ties stay with bits 0..127,
+    // so that uniform data always runs the same configuration); then the form, from that half's rate
+    const uint32_t lo = select[1], hi = select[2];
+    const bool use_hi = (double)hi * 1.25 < (double)lo;
+    select[3] = use_hi ? 1u : 0u;
+    const double rate = pairs ? (double)(use_hi ? hi : lo) / (double)pairs : 0.0;
     select[0] = rate * (double)pairs_per_step > 0.01 ? id_often : id_rare;
 }
 
@@ -695,7 +713,8 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
     }
 }
 
-// select[0] = form to run, select[1] = survivors counted by the probe, select[2..3] spare. One per process (all
+// select[0] = form to run, select[1] / select[2] = first-stage survivors the probe counted over bits 0..127 / 128..255,
+// select[3] = 1: the first stage runs on bits 128..255. One per process (all
 // launches go to the one library stream).
 static uint32_t* g_select = nullptr;
 // The hit context and the select words are shared device state written in stream order right before the kernels that

@@ -398,7 +398,21 @@ def test_k2_auto_variant_picks_the_form_from_the_data(gpu, hvd, oracle):
     assert len(want) >= 2
     assert np.array_equal(hvd.allpairs_hamming(st, 31), want)
     form, surv = _auto_form(gpu)
-    assert form == 12 and surv > 1000, (form, surv)
+    half = C.c_int(0)
+    gpu.check(gpu.load().hvd_debug_get(b"mfma_auto_half", C.byref(half)))
+    # round 3: the probe also picks WHICH 128 bits the first stage sees -- here the random upper half, where survivors
+    # are rare again, so the fetch form runs
+    assert half.value == 1 and form == 9 and surv > 1000, (form, surv, half.value)
+    # both halves structured (64 prototypes each): no half helps, the register form takes the survivors
+    st2 = st.copy()
+    st2[:, 16:] = rng.integers(0, 256, (64, 16), dtype=np.uint8)[rng.integers(0, 64, n)]
+    st2[:, 31] ^= rng.integers(0, 256, n, dtype=np.uint8)  # ... so that not 1/4096 of all pairs are exact duplicates
+    st2[5000] = st2[17]
+    want2 = oracle.allpairs(st2, 31, num_threads=8, cap=1 << 22)
+    assert np.array_equal(hvd.allpairs_hamming(st2, 31), want2)
+    form, surv = _auto_form(gpu)
+    gpu.check(gpu.load().hvd_debug_get(b"mfma_auto_half", C.byref(half)))
+    assert form == 12 and half.value == 0 and surv > 1000, (form, surv, half.value)
     # every explicit form agrees on the structured DB too (the fetch forms go through their survivor path all the time)
     from test_gpu_parity import _run_variant
 

@@ -184,3 +184,44 @@ def test_pinned_host_allocation_round_trip(gpu):
     assert np.array_equal(d.to_array(np.uint8, 1 << 20), src)
     d.free()
     gpu.check(lib.hvd_host_free(p))
+
+
+def test_k2_probe_moves_the_first_stage_to_the_more_selective_half(gpu, hvd, oracle):
+    """Frame hashes are not uniform: when one half of the bits barely separates unrelated hashes (here: bits 0..127
+    nearly constant across the DB), the probe puts the 128-bit first stage on the OTHER half. Same pair list either way."""
+    rng = np.random.default_rng(47)
+    n = 6000
+    db = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    common = rng.integers(0, 256, 16, dtype=np.uint8)
+    low = np.tile(common, (n, 1))
+    low = hvd.synth.flip_bits(np.concatenate([low, np.zeros((n, 16), np.uint8)], axis=1), rng.integers(0, 9, n), rng)[:, :16]
+    db[:, :16] = low  # bits 0..127: a common pattern with 0..8 flips -> any two agree within 16 bits there
+    src = rng.choice(n // 2, 300, replace=False)
+    db[n // 2: n // 2 + 300] = hvd.synth.flip_bits(db[src], rng.integers(0, 40, 300), rng)
+    want = oracle.allpairs(db, 31)
+    assert 150 < len(want) < 400
+    lib = gpu.load()
+
+    def auto_half(d):
+        got = hvd.search.allpairs_hamming(d, 31)
+        v = C.c_int(0)
+        gpu.check(lib.hvd_debug_get(b"mfma_auto_half", C.byref(v)))
+        lo, hi = C.c_int(0), C.c_int(0)
+        gpu.check(lib.hvd_debug_get(b"mfma_probe_survivors", C.byref(lo)))
+        gpu.check(lib.hvd_debug_get(b"mfma_probe_survivors_hi", C.byref(hi)))
+        return got, v.value, lo.value, hi.value
+
+    got, half, lo, hi = auto_half(db)
+    assert np.array_equal(got, want)
+    assert half == 1 and lo > 100 * max(hi, 1)
+    # mirrored DB (the degenerate half on top): the first stage stays on bits 0..127
+    mirrored = np.ascontiguousarray(np.concatenate([db[:, 16:], db[:, :16]], axis=1))
+    got_m, half_m, lo_m, hi_m = auto_half(mirrored)
+    assert np.array_equal(got_m, oracle.allpairs(mirrored, 31)) and half_m == 0 and hi_m > 100 * max(lo_m, 1)
+    # uniform DB: no preference, bits 0..127
+    uni, _ = hvd.synth.hash_db(6000, seed=48)
+    got_u, half_u, _, _ = auto_half(uni)
+    assert half_u == 0 and np.array_equal(got_u, oracle.allpairs(uni, 31))
+    # and the video-level search on the degenerate library
+    off = np.arange(0, n + 1, 20, dtype=np.int64)
+    assert np.array_equal(hvd.match_videos(db, off, 31), oracle.match_videos(db, off, 31))
