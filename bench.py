@@ -296,6 +296,21 @@ def main():
         # over the control channel (reported in the JSON) instead of producing no measurement at all.
         exchange, why, hard_exit = M.connect_rccl(rdzv, float(os.environ.get("HVD_RCCL_INIT_TIMEOUT", "120")))
         if exchange is not None:
+            # the communicator exists; can it move data? One 16-byte all-gather under a deadline decides for all ranks.
+            ok, why, stuck = M.preflight_rccl(rdzv, exchange, float(os.environ.get("HVD_RCCL_PREFLIGHT_TIMEOUT", "60")))
+            if not ok:
+                hard_exit = hard_exit or stuck
+                # ncclCommAbort also unblocks a collective that hangs on the device (it sits on the library stream, which
+                # the kernels need); bounded, because nothing here may be able to hang the measurement
+                import threading
+
+                ab = threading.Thread(target=lambda: exchange.abort(), daemon=True)
+                ab.start()
+                ab.join(30.0)
+                hard_exit = hard_exit or ab.is_alive()
+                exchange = None
+                why = "preflight all-gather " + why
+        if exchange is not None:
             exchange_kind = "rccl"
         else:
             print(f"[bench] rank {rank}: RCCL init {why}; exchanging candidates over TCP", file=sys.stderr)

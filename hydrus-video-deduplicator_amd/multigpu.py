@@ -150,6 +150,34 @@ def connect_rccl(rdzv, timeout: float = 120.0):
     return None, why, th.is_alive()
 
 
+def preflight_rccl(rdzv, exchange: RcclExchange, timeout: float = 60.0):
+    """Collective: one tiny all-gather of candidate pairs through the freshly formed communicator, under a deadline, and
+    the ranks' verdicts combined over the control channel. -> (ok, reason, stuck). A communicator that initialises but
+    cannot move data (fabric / IPC configuration) must degrade the exchange path, not hang the first real pass."""
+    import threading
+
+    box = {}
+
+    def _go():
+        try:
+            d = _lib.DeviceBuffer(16)
+            d.zero()
+            got = exchange.allgather_pairs_dev(d.ptr, 1)
+            box["ok"] = len(got) == exchange.world
+            d.free()
+        except Exception as exc:  # noqa: BLE001
+            box["err"] = exc
+
+    th = threading.Thread(target=_go, daemon=True)
+    th.start()
+    th.join(timeout)
+    mine = 1.0 if (box.get("ok") and not th.is_alive()) else 0.0
+    if rdzv.allreduce_min([mine])[0] >= 1.0:
+        return True, "ok", False
+    why = "timed out" if th.is_alive() else repr(box.get("err", "wrong record count" if "ok" in box else "failed on another rank"))
+    return False, why, th.is_alive()
+
+
 def launch_allpairs(lib, d_db_ptr: int, d_img_ptr: int | None, n: int, d_group_ptr, max_dist: int, rank: int,
                     world: int, d_pairs_ptr: int, cap: int, d_cnt_ptr: int, variant: int) -> None:
     """Enqueue one all-pairs pass of this rank's tiles (popcount variants 0..6 on the packed DB,

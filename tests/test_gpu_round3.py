@@ -225,3 +225,15 @@ def test_k2_probe_moves_the_first_stage_to_the_more_selective_half(gpu, hvd, ora
     # and the video-level search on the degenerate library
     off = np.arange(0, n + 1, 20, dtype=np.int64)
     assert np.array_equal(hvd.match_videos(db, off, 31), oracle.match_videos(db, off, 31))
+
+
+def test_rccl_preflight_passes_on_a_world_1_communicator(gpu, hvd):
+    """bench.py's guard in front of the first real exchange: one 16-byte all-gather under a deadline."""
+    from hvd_amd.rendezvous import Rendezvous
+
+    ex = hvd.multigpu.RcclExchange(0, 1, hvd.multigpu.RcclExchange.create_unique_id())
+    try:
+        ok, why, stuck = hvd.multigpu.preflight_rccl(Rendezvous(0, 1), ex, timeout=60.0)
+        assert ok and not stuck, why
+    finally:
+        ex.close()
