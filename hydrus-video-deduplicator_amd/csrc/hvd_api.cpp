@@ -240,6 +240,7 @@ int hvd_shutdown(void) {
     if (g.m_pin) (void)hipHostFree(g.m_pin);
     hvd::stream_release_cache();
     hvd::mfma_release();
+    hvd::pdq_release();
     g.~Ctx();
     new (&g) Ctx();
     return HVD_OK;

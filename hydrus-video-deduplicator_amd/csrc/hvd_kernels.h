@@ -38,6 +38,7 @@ hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_
                              const int32_t* d_group_t, hipStream_t s);
 hipError_t mfma_select_buffer(uint32_t** out);  // [0] = form the auto variant ran last, [1] = probe survivors
 void mfma_release();
+void pdq_release();           // k_pdq.hip: free the hash kernel's work-counter ring (hvd_shutdown)
 void stream_release_cache();  // hvd_stream.cpp: free the parked hasher slot sets (hvd_shutdown)
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 

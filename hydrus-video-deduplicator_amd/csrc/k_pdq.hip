@@ -25,6 +25,9 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "hvd_kernels.h"
 
 namespace {
@@ -104,11 +107,20 @@ __device__ __forceinline__ constexpr float dct_lit(int i, int k) { return __buil
 // products). 2: 32-bit LITERALS in the instruction stream -- the matrix is a constant of the algorithm, so stage 1 is
 // unrolled completely (16 x 64 multiply-adds, ~20 KB of code) and every multiply carries its coefficient: no operand
 // fetch at all, full-rate issue.
+// Work distribution (round 3): a workgroup takes chunk blockIdx.x (`chunk` consecutive groups of 4 frames) statically and
+// every further chunk from a counter in device memory, so that no workgroup is left with a trip more than its neighbours
+// while their SIMDs idle (at 400 k frames the static stride cost 16 %). One atomic per trip, ISSUED at the top of the trip
+// and CONSUMED at its end: same-address device atomics serialise at ~8 ns each, and a thousand workgroups draw at once when
+// a launch starts -- which is why launches below 64 k frames keep the static stride (work == nullptr): measured, the draws cost
+// 10 k frames 52 -> 65 us, while 400 k frames gain 12 % (profiles/r03_k1_grid.txt). Every trip draws exactly once, so the draw that returns (trips - 1) is the last of the launch: its
+// workgroup zeroes the counter for the next launch that is handed this slot -- no exit counter.
 template <int KIND, int DLDS, int LUT>
 __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in, long long n,
                                                     const float* __restrict__ dct, uint8_t* __restrict__ hashes,
-                                                    int32_t* __restrict__ quality) {
+                                                    int32_t* __restrict__ quality, unsigned int* __restrict__ work,
+                                                    int chunk) {
     __shared__ PdqLds lds;
+    __shared__ unsigned int next_chunk;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -118,7 +130,11 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
     __syncthreads();
 
     const long long groups = (n + kWaves - 1) / kWaves;
-    for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
+    const long long nchunks = (groups + chunk - 1) / chunk;
+    for (long long ck = blockIdx.x; ck < nchunks;) {
+        unsigned int drawn = 0;
+        if (work != nullptr && threadIdx.x == 0) drawn = atomicAdd(&work[0], 1u);  // consumed behind this trip's last group
+      for (long long g = ck * chunk; g < groups && g < (ck + 1) * chunk; ++g) {
         const long long f = g * kWaves + wave;
         const bool valid = f < n;  // wave-uniform
 
@@ -291,6 +307,18 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             }
         }
         __syncthreads();  // T is rewritten by the next trip
+      }
+        if (work == nullptr) {  // short launches stride statically: a thousand workgroups drawing at once wait on each other
+            ck += gridDim.x;
+            continue;
+        }
+        if (threadIdx.x == 0) {
+            next_chunk = gridDim.x + drawn;
+            if ((long long)drawn == nchunks - 1) work[0] = 0u;  // the launch's last draw: nobody will touch the counter again
+        }
+        __syncthreads();
+        ck = next_chunk;
+        __syncthreads();  // (everyone has read next_chunk before thread 0 overwrites it at the end of the next trip)
     }
 }
 
@@ -1376,17 +1404,47 @@ bool pdq_dct_table_matches(const float* host_16x64) {
     return true;
 }
 
+// Work counters of k_pdq_hash64: a ring of self-cleaning slots (the last workgroup of a launch zeroes its slot), one per
+// launch in flight -- the streaming hasher runs up to three launches concurrently on its own streams.
+static unsigned int* g_hash_work = nullptr;
+static std::atomic<unsigned int> g_hash_work_next{0};
+constexpr unsigned int kHashWorkSlots = 256;
+
+void pdq_release() {
+    if (g_hash_work) (void)hipFree(g_hash_work);
+    g_hash_work = nullptr;
+}
+
 hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
                              int32_t* d_quality, hipStream_t s) {
     if (n <= 0) return hipSuccess;
+    if (!g_hash_work) {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!g_hash_work) {
+            unsigned int* p = nullptr;
+            hipError_t e = hipMalloc((void**)&p, kHashWorkSlots * 2 * sizeof(unsigned int));
+            if (e != hipSuccess) return e;
+            e = hipMemset(p, 0, kHashWorkSlots * 2 * sizeof(unsigned int));
+            if (e != hipSuccess) return e;
+            g_hash_work = p;
+        }
+    }
     const int64_t groups = (n + kWaves - 1) / kWaves;
-    // 93-100 VGPRs = 4 (5 for the literal form) waves per SIMD: below 64 k frames the grid is what is resident at once,
-    // 4 workgroups per CU, so that no second dispatch round of a few workgroups trails the launch (round 3, 10 k frames:
-    // 1024 workgroups 51-52 us, 1792 54-55 us, profiles/r03_k1_grid.txt); long launches keep 7 per CU (LDS limit), where
-    // workgroups that retire early make room for the rest.
+    // literals from 8 k frames on (round 3: with the leaner quality term the literal form also wins at 10 k frames)
+    const int dlds = g_pdq_dct_from_lds == 3 ? (n >= 8192 ? 2 : 0) : g_pdq_dct_from_lds;
+    const int lut = g_pdq_luma_lut;
+    // long launches of the strict kernels distribute their work dynamically (see the kernel), several groups per draw
+    const bool dynamic = g_pdq_dct_mode != 1 && n >= 65536;
+    unsigned int* work = dynamic ? g_hash_work + 2u * (g_hash_work_next.fetch_add(1u) % kHashWorkSlots) : nullptr;
+    const int chunk = !dynamic ? 1 : n >= (1 << 20) ? 8 : 4;
+    const int64_t nchunks = (groups + chunk - 1) / chunk;
+    // 92-100 VGPRs = 4 (5 for the literal form) waves per SIMD. Static stride below 64 k frames: the grid is what is resident
+    // at once, 4 workgroups per CU, so that no second dispatch round of a few workgroups trails the launch (10 k frames: 1024
+    // workgroups 51-52 us, 1792 54-55 us); dynamic: 7 per CU (the LDS limit; 1792 measured best); fma kernel: static, 7 per CU.
     const int64_t max_grid = n < 65536 ? 256 * 4 : 256 * 7;
-    dim3 grid((unsigned)(groups < max_grid ? groups : max_grid));
-    if (g_pdq_hash_grid > 0) grid.x = (unsigned)(groups < g_pdq_hash_grid ? groups : g_pdq_hash_grid);
+    dim3 grid((unsigned)(nchunks < max_grid ? nchunks : max_grid));
+    if (g_pdq_hash_grid > 0) grid.x = (unsigned)(nchunks < g_pdq_hash_grid ? nchunks : g_pdq_hash_grid);
     if (g_pdq_dct_mode == 1) {
         if (kind == 0)
             hipLaunchKernelGGL(k_pdq_hash64_fma<0>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
@@ -1394,10 +1452,7 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
             hipLaunchKernelGGL(k_pdq_hash64_fma<1>, grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality);
         return hipGetLastError();
     }
-    // literals from 8 k frames on (round 3: with the leaner quality term the literal form also wins at 10 k frames)
-    const int dlds = g_pdq_dct_from_lds == 3 ? (n >= 8192 ? 2 : 0) : g_pdq_dct_from_lds;
-    const int lut = g_pdq_luma_lut;
-#define HVD_K1(KIND, D, L) hipLaunchKernelGGL((k_pdq_hash64<KIND, D, L>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality)
+#define HVD_K1(KIND, D, L) hipLaunchKernelGGL((k_pdq_hash64<KIND, D, L>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality, work, chunk)
     if (kind == 0) {
         if (dlds == 2) HVD_K1(0, 2, 1);
         else if (dlds == 1) HVD_K1(0, 1, 1);
