@@ -1081,6 +1081,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
 #pragma unroll
     for (int q = 0; q < SQ; ++q) fifo[q] = make_uint4(0, 0, 0, 0);
 
+    // (frames strided by the grid; handing them out dynamically, as k_pdq_hash64 does for long launches, was measured:
+    // no gain at 6144 frames -- the kernel waits on the memory side -- and a longer tail at sizes that are not a multiple
+    // of the resident waves)
     for (long long f = blockIdx.x; f < n; f += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rd = make_rsrc(out64 + (size_t)f * 4096, 4096 * sizeof(float));
         float sD = 0.0f, dl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1415,9 +1418,8 @@ void pdq_release() {
     g_hash_work = nullptr;
 }
 
-hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
-                             int32_t* d_quality, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
+// the next self-cleaning counter slot of the ring (allocated and zeroed on first use)
+static hipError_t work_slot(unsigned int** out) {
     if (!g_hash_work) {
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
@@ -1430,13 +1432,24 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
             g_hash_work = p;
         }
     }
+    *out = g_hash_work + 2u * (g_hash_work_next.fetch_add(1u) % kHashWorkSlots);
+    return hipSuccess;
+}
+
+hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
+                             int32_t* d_quality, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
     const int64_t groups = (n + kWaves - 1) / kWaves;
     // literals from 8 k frames on (round 3: with the leaner quality term the literal form also wins at 10 k frames)
     const int dlds = g_pdq_dct_from_lds == 3 ? (n >= 8192 ? 2 : 0) : g_pdq_dct_from_lds;
     const int lut = g_pdq_luma_lut;
     // long launches of the strict kernels distribute their work dynamically (see the kernel), several groups per draw
     const bool dynamic = g_pdq_dct_mode != 1 && n >= 65536;
-    unsigned int* work = dynamic ? g_hash_work + 2u * (g_hash_work_next.fetch_add(1u) % kHashWorkSlots) : nullptr;
+    unsigned int* work = nullptr;
+    if (dynamic) {
+        hipError_t e = work_slot(&work);
+        if (e != hipSuccess) return e;
+    }
     const int chunk = !dynamic ? 1 : n >= (1 << 20) ? 8 : 4;
     const int64_t nchunks = (groups + chunk - 1) / chunk;
     // 92-100 VGPRs = 4 (5 for the literal form) waves per SIMD. Static stride below 64 k frames: the grid is what is resident
