@@ -1450,12 +1450,14 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
         hipError_t e = work_slot(&work);
         if (e != hipSuccess) return e;
     }
-    const int chunk = !dynamic ? 1 : n >= (1 << 20) ? 8 : 4;
+    const int chunk = !dynamic ? 1 : n >= (1 << 20) ? 8 : n >= (1 << 18) ? 4 : 1;
     const int64_t nchunks = (groups + chunk - 1) / chunk;
     // 92-100 VGPRs = 4 (5 for the literal form) waves per SIMD. Static stride below 64 k frames: the grid is what is resident
     // at once, 4 workgroups per CU, so that no second dispatch round of a few workgroups trails the launch (10 k frames: 1024
     // workgroups 51-52 us, 1792 54-55 us); dynamic: 7 per CU (the LDS limit; 1792 measured best); fma kernel: static, 7 per CU.
-    const int64_t max_grid = n < 65536 ? 256 * 4 : 256 * 7;
+    // (16 k - 64 k frames: static stride over 7 per CU -- more workgroups than are resident, so the hardware's own
+    // dispatch evens the load out: 20 k frames 97 -> 86 us)
+    const int64_t max_grid = n < 16384 ? 256 * 4 : 256 * 7;
     dim3 grid((unsigned)(nchunks < max_grid ? nchunks : max_grid));
     if (g_pdq_hash_grid > 0) grid.x = (unsigned)(nchunks < g_pdq_hash_grid ? nchunks : g_pdq_hash_grid);
     if (g_pdq_dct_mode == 1) {

@@ -5,7 +5,7 @@ import ctypes as C, numpy as np, hvd_amd
 from hvd_amd import _lib as L, synth
 lib = L.init(0)
 fr = synth.frames_gray(10000, seed=2)
-for nf in (1000, 4000, 8192, 10000, 20000, 65536, 400000):
+for nf in [int(x) for x in os.environ.get("NS", "1000,4000,8192,10000,20000,65536,400000").split(",")]:
     d_f = L.DeviceBuffer(nf * 4096)
     for r0 in range(0, nf, 10000):
         m = min(10000, nf - r0)
