@@ -27,6 +27,7 @@ done
 bash scripts/profile_rgb.sh r03_rgb 2 stats sq1 sq2 fetch wr tcc > /dev/null 2>&1
 python scripts/pmc_summary.py gpurun_out/pmc_r03_rgb > gpurun_out/r03_pmc_down512w.txt 2>&1
 # structured K2 A/B: register form (variant 12) on config-5-style frame hashes, cascade on / off
+# (needs: bash scripts/build_variant.sh nocascade k_hamming_mfma.hip -DHVD_K2_CASCADE=0)
 for LIBTAG in default nocascade; do
   O3=$OUT/pmc_r03_k2s_$LIBTAG; mkdir -p $O3
   LIBENV=""; [ $LIBTAG = nocascade ] && LIBENV="HVD_LIB_PATH=$REPO/build_tmp/libhvd_nocascade.so"
