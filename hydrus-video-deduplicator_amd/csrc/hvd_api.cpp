@@ -361,6 +361,16 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_mfma_col_chunk_max = (uint32_t)value;
         return HVD_OK;
     }
+    if (strcmp(key, "mfma_auto_mid") == 0) {  // form the auto variant runs on data with common false survivors
+        if (value != 0 && value != 15) return fail(HVD_ERR_ARG, "mfma_auto_mid: 15 (pair-queue form) or 0 (none: fetch or register form only)");
+        hvd::g_mfma_auto_mid = (uint32_t)value;
+        return HVD_OK;
+    }
+    if (strcmp(key, "mfma_auto_mid_max_x100") == 0) {  // ... up to this many survivors per 1024-pair tile (x 0.01)
+        if (value < 0) return fail(HVD_ERR_ARG, "mfma_auto_mid_max_x100 must not be negative");
+        hvd::g_mfma_auto_mid_max_x100 = (uint32_t)value;
+        return HVD_OK;
+    }
     if (strcmp(key, "pdq_down512_wave") == 0) {
         if (value < 0 || value > 2) return fail(HVD_ERR_ARG, "pdq_down512_wave: 0 never, 1 by batch size, 2 always");
         hvd::g_pdq_down512_wave = value;
@@ -408,6 +418,18 @@ int hvd_debug_get(const char* key, int* out_value) {
             *out_value = (int)v[k];
             return HVD_OK;
         }
+    if (strncmp(key, "mfma_qstat", 10) == 0 && key[10] >= '0' && key[10] <= '9') {  // HVD_K2_QSTATS builds (dev tool); reading clears
+        const int k = atoi(key + 10);
+        if (k < 0 || k > 15) return fail(HVD_ERR_ARG, "mfma_qstat0..15");
+        uint32_t* sel = nullptr;
+        HIP_TRY(hvd::mfma_select_buffer(&sel));
+        unsigned long long v = 0;
+        HIP_TRY(hipMemcpyAsync(&v, sel + 128 + 2 * k, 8, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipMemsetAsync(sel + 128 + 2 * k, 0, 8, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        *out_value = (int)(v > 0x7FFFFFFFull ? 0x7FFFFFFF : v);
+        return HVD_OK;
+    }
     return fail(HVD_ERR_ARG, "unknown debug key %s", key);
 }
 

@@ -10,7 +10,8 @@
 namespace hvd {
 
 struct AllPairsArgs {
-    const void* d_db;        // n * 32 bytes
+    const void* d_db;        // n * 32 bytes (FP4-MFMA forms: optional, the packed hashes of the image's rows)
+    const void* d_db_q = nullptr;  // rectangular form: the packed query hashes (optional)
     uint32_t n;
     const int32_t* d_group;  // nullable
     uint32_t max_dist;
@@ -29,6 +30,7 @@ bool allpairs_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32
 // FP4-MFMA form (k_hamming_mfma.hip), variants 8..11. d_img: fp4_rows_padded(n)*128 bytes.
 uint32_t fp4_rows_padded(uint32_t n);
 extern uint32_t g_mfma_col_chunk_max;
+extern uint32_t g_mfma_auto_mid, g_mfma_auto_mid_max_x100;
 extern uint32_t g_fp4_code;
 hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s);
 hipError_t launch_allpairs_mfma(const AllPairsArgs& a, const void* d_img, hipStream_t s);

@@ -183,6 +183,12 @@ struct HitCtx {
     float thr_full, inv_scale2;
     uint32_t rect;
     float acc_start;  // start value of the launched form's accumulators (see or16_bits)
+    const uint4* img_q;  // FP4 images of the rows / of the columns (the pair queue's drain reads single hashes from them)
+    const uint4* img_t;
+    const uint4* db_q;  // the same hashes packed (32 B each), nullable: the drain's cheaper source (2 loads per hash instead of 8)
+    const uint4* db_t;
+    uint32_t max_dist;
+    unsigned long long* qstats;  // HVD_K2_QSTATS builds only: counters of the pair queue's routes (dev tool)
 };
 
 // Hits of one 32x32 tile whose accumulators hold the full 256-bit dot products: acc[r] belongs to
@@ -328,6 +334,94 @@ __device__ __noinline__ void panel_survivors(uint32_t marks, const uint4* __rest
     }
 }
 
+
+// ---- pair queue (round 4): what a false first-stage survivor costs -------------------------------------------------
+// On real frame hashes 2.3e-4 of all pairs pass the 128-bit first stage (0.24 per 1024-pair tile) although only ~1e-8 are
+// hits. Every MFMA-based way of settling them spends matrix-pipe time on a whole 32x32 tile for ONE pair: +1 MFMA per
+// survivor in the register cascade (+11 % MFMAs and a dependent chain), 4 from memory in the fetch form. The queue form
+// spends none: the lanes that hold a surviving accumulator push (row, column) -- 4 bytes -- into a per-wave LDS queue, and
+// whenever 64 have gathered the wave settles them on the VALU, one pair per lane: the two FP4 images differ exactly in the
+// sign nibbles of differing bits, so hamming = popcount(x ^ y) over the 8 chunks. The matrix pipe never sees a survivor,
+// the query fragments stay at 128 bits (64 VGPRs at 8 tiles: the fetch form's MFMAs per B-fragment read), and the VALU,
+// which idles at ~35 % in this kernel, absorbs ~40 instructions per surviving tile + ~1.5 per settled pair.
+// A tile with MANY survivors (a real cluster, the diagonal, two copies of one video) still goes the tile route
+// (panel_survivors: full recomputation + the tile-level hit handler with its video-key de-duplication).
+// The queues are per wave (slots are handed out with a scalar counter, no atomics), but they are SETTLED by the whole
+// workgroup, right behind a super-panel barrier: a wave that settles its own queue sits out two memory round trips while its
+// three siblings run into the next barrier and wait for it (first version: SQ_WAIT_ANY +50 %, matrix pipe 0.50 busy). Behind
+// a barrier everybody is in step anyway; 256 lanes take one entry each, one round trip, every ~7 super-panels.
+constexpr uint32_t kQTileLanes = 4;   // a tile with survivors in more lanes (columns x halves) than this takes the tile route (4e-4 of the surviving tiles of frame hashes)
+constexpr uint32_t kQWaveCap = 256;   // entries per wave
+constexpr uint32_t kQSuperMax = (kSuper / 32) * 8 * kQTileLanes;  // most that one wave can add between two barriers
+constexpr uint32_t kQDrainAt = 192;   // settle when the workgroup holds this many (or a wave could overflow before the next barrier)
+// entry: x = survivor mask of the lane's 16 accumulator registers (bit 15 - r <-> register r) | (first row of the lane,
+// relative to the workgroup's first row: wave * rows per wave + 32 t + 4 h) << 16; y = column (absolute)
+__shared__ uint2 g_wave_queue[4][kQWaveCap];
+__shared__ __attribute__((aligned(16))) uint32_t g_wave_qn[4];
+
+__device__ __forceinline__ uint32_t sign_popc(const uint4& x, const uint4& y, uint32_t acc) {
+    // equal magnitude bits cancel: only sign nibbles survive the XOR (rows beyond n are FP4 zeros -- filtered by index)
+    return acc + __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
+}
+
+// Settle all four queues (n0..n3 entries). Called by all 256 threads behind a barrier; the caller puts another barrier
+// behind it before anybody pushes again.
+__device__ __noinline__ void drain_queues_wg(const HitCtx* __restrict__ ctx, uint32_t n0_v, uint32_t n1_v, uint32_t n2_v,
+                                             uint32_t n3_v, uint32_t row0_v, uint32_t tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0_v), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1_v);
+    const uint32_t n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n2_v), n3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n3_v);
+    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
+#else
+    const uint32_t n0 = n0_v, n1 = n1_v, n2 = n2_v, n3 = n3_v, row0 = row0_v;
+#endif
+    const HitCtx c = load_ctx(ctx);
+    const bool rect = c.rect != 0u;
+    const uint32_t total = n0 + n1 + n2 + n3;
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < total; k0 += 256u) {
+        const uint32_t k = k0 + tid;
+        if (k >= total) continue;
+        const uint32_t w = k < n0 ? 0u : k < n0 + n1 ? 1u : k < n0 + n1 + n2 ? 2u : 3u;
+        const uint32_t idx = k - (w == 0u ? 0u : w == 1u ? n0 : w == 2u ? n0 + n1 : n0 + n1 + n2);
+        const uint2 e = g_wave_queue[w][idx];
+        uint32_t m = e.x & 0xFFFFu;
+        const uint32_t ib = row0 + (e.x >> 16), j = e.y;
+        const int32_t gcol = c.group != nullptr && j < c.n ? (rect ? c.group_t[j] : c.group[j]) : 0;
+#pragma unroll 1
+        while (m != 0u) {
+            const uint32_t bit = 31u - (uint32_t)__clz((int)m);
+            m &= ~(1u << bit);
+            const uint32_t r = 15u - bit;
+            const uint32_t i = ib + (r & 3u) + 8u * (r >> 2);
+            uint32_t d = 0;
+            if (c.db_t != nullptr) {  // launch-uniform
+                const uint4 x0 = c.db_q[(size_t)i * 2u], x1 = c.db_q[(size_t)i * 2u + 1u];
+                const uint4 y0 = c.db_t[(size_t)j * 2u], y1 = c.db_t[(size_t)j * 2u + 1u];
+                d = sign_popc(x0, y0, sign_popc(x1, y1, 0u));
+            } else {
+                const uint4* __restrict__ pi = c.img_q + (size_t)i * 8u;
+                const uint4* __restrict__ pj = c.img_t + (size_t)j * 8u;
+                const uint32_t si = (i >> 1) & 7u, sj = (j >> 1) & 7u;
+#pragma unroll 1
+                for (uint32_t c0 = 0; c0 < 8u; c0 += 4u) {
+#pragma unroll
+                    for (uint32_t ch = c0; ch < c0 + 4u; ++ch) d = sign_popc(pi[ch ^ si], pj[ch ^ sj], d);
+                }
+            }
+            bool ok = d <= c.max_dist && j < c.n && (rect ? i < c.nq : i < j);
+            if (ok && c.group != nullptr) ok = c.group[i] != gcol;
+            if (!ok) continue;
+            if (c.vs.set == nullptr) {
+                append_pair_wg(c.out, c.cap, c.count, i, j, d);
+            } else {
+                hvd::sink_insert(c.vs, hvd::vkey_make(0u, i, (uint32_t)c.vs.vid_t[j]));
+                hvd::sink_insert(c.vs, hvd::vkey_make(rect ? 1u : 0u, j, (uint32_t)c.vs.vid_q[i]));
+            }
+        }
+    }
+}
+
 // Stage one 16 KB super-panel (128 hashes x 128 B, contiguous in the image) into LDS with
 // direct global->LDS loads: each wave-instruction moves 64 lanes x 16 B = 1 KB to a
 // wave-uniform LDS base + lane*16, no VGPR round trip (so nothing to keep live -- or spill --
@@ -357,15 +451,18 @@ __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src,
 // stage / hit handler work on exactly that tile's accumulators -- nothing is recomputed.
 // RECT = false: img_q == img (one set, strict upper triangle). RECT = true: rows come from the
 // query image img_q (nq hashes), candidates from the target image img (n hashes), full rectangle.
-template <int TILES, int NBR, int S1, bool RECT>
+//   QUEUE  (NBR = S1 = 2 only) first-stage survivors are settled pair by pair on the VALU (pair queue, above) instead of
+//          tile by tile on the matrix pipe: the form for data on which false survivors are common (real frame hashes).
+template <int TILES, int NBR, int S1, bool RECT, bool QUEUE = false>
 // (the 4-tile register form is held to 3 waves per SIMD = 168 VGPRs: with the pre-read fragment it would take 170)
-__global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
+__global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
                                                           uint32_t max_dist, uint32_t col_chunk, uint32_t rank,
                                                           uint32_t world, const uint4* __restrict__ img_q, float scale2,
                                                           const HitCtx* __restrict__ ctx,
                                                           const uint32_t* __restrict__ select, uint32_t select_id) {
     static_assert(S1 == 2 || S1 == 4, "first stage = 128 or 256 bits");
     static_assert(NBR >= S1 && (NBR == 2 || NBR == 4), "register-resident k-steps");
+    static_assert(!QUEUE || (NBR == 2 && S1 == 2 && TILES <= 8), "the pair queue belongs to the 128-bit fetch form");
     constexpr uint32_t WROWS = 32u * TILES, ROWS = 4u * WROWS;
     __shared__ uint4 lds0[kSuper * 8], lds1[kSuper * 8];
 
@@ -428,6 +525,7 @@ __global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) v
     const uint32_t nsp = (col1 - j0) / kSuper;  // col0, col1, j0 are multiples of kSuper
 
     const v16f zero = {c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1};  // the accumulators' start value
+    uint32_t qn = 0;  // QUEUE: entries waiting in this wave's pair queue (wave-uniform)
 
     // The two LDS buffers are separate objects and the super-panel loop is unrolled by two, so that every
     // ds_read names one array and every in-flight global->LDS load the other: with one two-dimensional array
@@ -450,7 +548,75 @@ __global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) v
             if constexpr (NBR == 4 && S1 == 2 && kCascade) b192 = as_v4i(base[(4u + h) ^ sw]);
 
             // two accumulator sets: the MFMAs of tile t+1 are issued before the max tree of tile t
-            if constexpr (NBR == 2) {
+            if constexpr (QUEUE) {
+                // Each tile is judged while its accumulators are live; a surviving tile hands its few surviving PAIRS to the
+                // wave's queue (or, when there are many, its index to the tile route) and the matrix pipe moves on.
+                uint32_t tmarks = 0;  // wave-uniform: bit (TILES-1-t) <-> tile t takes the tile route
+                auto note = [&](const int t, const v16f& acc) {
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 1  // timing-only ablations (wrong results): 1 = a surviving tile is ignored
+                    return;
+#endif
+                    // ~22 VALU instructions: this kernel has ~10 VALU issue slots to spare per tile and a fifth of all tiles
+                    // of a frame-hash library come here, so every instruction of this path is on the clock
+                    uint32_t ma = 0, mb = 0;  // two independent chains; bit (15 - r) of the result <-> accumulator register r
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 4  // 4 = a 6-bit mask instead of 16 bits (what a group mask would cost)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+#else
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+#endif
+                        if (kSign) {
+                            ma = __builtin_amdgcn_alignbit(ma, (uint32_t)__float_as_int(acc[r]), 31);
+                            mb = __builtin_amdgcn_alignbit(mb, (uint32_t)__float_as_int(acc[r + 8]), 31);
+                        } else {
+                            ma = (ma << 1) | (__float_as_int(acc[r]) >= thr1_bits ? 1u : 0u);
+                            mb = (mb << 1) | (__float_as_int(acc[r + 8]) >= thr1_bits ? 1u : 0u);
+                        }
+                    }
+                    const uint32_t m = (ma << 8) | mb;
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 2  // 2 = the mask is built, nothing is pushed
+                    asm volatile("" ::"v"(m));
+                    return;
+#endif
+                    const unsigned long long act = __ballot(m != 0u);
+                    // (two 32-bit counts: with the 64-bit one the compare below lands on the VALU)
+                    const uint32_t nl = (uint32_t)__builtin_popcount((uint32_t)act) + (uint32_t)__builtin_popcount((uint32_t)(act >> 32));
+#ifdef HVD_K2_QSTATS
+                    {
+                        const HitCtx cs = load_ctx(ctx);
+                        uint32_t tot = __popc(m);
+                        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
+                        if (lane == 0u) {
+                            atomicAdd(&cs.qstats[0], 1ull);
+                            atomicAdd(&cs.qstats[3], (unsigned long long)tot);
+                            if (nl > kQTileLanes) atomicAdd(&cs.qstats[1], 1ull);
+                            const uint32_t b = tot <= 1 ? 8 : tot <= 2 ? 9 : tot <= 4 ? 10 : tot <= 8 ? 11 : tot <= 16 ? 12 : tot <= 32 ? 13 : tot <= 64 ? 14 : 15;
+                            atomicAdd(&cs.qstats[b], 1ull);
+                        }
+                    }
+#endif
+                    if (nl > kQTileLanes) {
+                        tmarks |= 1u << (TILES - 1 - t);
+                        return;
+                    }
+                    if (m != 0u) {
+                        const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                        g_wave_queue[wave][slot] = make_uint2(m | ((wave * WROWS + 32u * (uint32_t)t + 4u * h) << 16), jsp + cl);
+                    }
+                    qn += nl;
+                };
+                v16f cur = tile_dot<0, S1>(a[0], b, zero);
+#pragma unroll
+                for (int t = 1; t < TILES; ++t) {
+                    const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
+                    if (__builtin_expect(stage1_hit(cur), 0)) note(t - 1, cur);
+                    cur = nxt;
+                }
+                if (__builtin_expect(stage1_hit(cur), 0)) note(TILES - 1, cur);
+                // (both calls sit where no accumulator is live: the handlers' registers add to the live set across a call)
+                if (__builtin_expect(tmarks != 0u, 0)) panel_survivors<TILES>(tmarks, imgq, panel, wrow0, jsp + 32u * p, lane, ctx);
+            } else if constexpr (NBR == 2) {
                 // survivors are only noted -- one VALU op per tile shifts the tile's verdict (the sign of the OR, or the
                 // compare's result) into a per-lane mask -- and dealt with after the panel, when no accumulator is live
                 // any more: the handler's registers add to whatever is live across its call. One compare per PANEL.
@@ -498,6 +664,29 @@ __global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) v
         }
     };
 
+    // QUEUE: every wave publishes its fill level in front of a super-panel barrier; behind it the workgroup decides -- on
+    // the same four numbers -- whether to settle the queues now (drain_queues_wg).
+    auto publish = [&]() {
+        if constexpr (QUEUE) {
+            if (lane == 0u) g_wave_qn[wave] = qn;
+        }
+    };
+    auto settle = [&](const bool final) {
+        if constexpr (QUEUE) {
+            const uint4 q4 = *reinterpret_cast<const uint4*>(g_wave_qn);
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.x), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.y);
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.z), n3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.w);
+            const uint32_t sum = n0 + n1 + n2 + n3, mx = max(max(n0, n1), max(n2, n3));
+            if (final ? sum != 0u : (sum >= kQDrainAt || mx > kQWaveCap - kQSuperMax)) {
+#if !(defined(HVD_K2_QABL) && HVD_K2_QABL == 3)  // 3 = pushed entries are dropped instead of settled
+                drain_queues_wg(ctx, n0, n1, n2, n3, row0, wave * 64u + lane);
+#endif
+                qn = 0;
+                __syncthreads();  // nobody pushes (or publishes) again before everybody has read the queues
+            }
+        }
+    };
+
     stage_super_panel(img + (size_t)j0 * 8u, lds0, wave, lane);
     __syncthreads();
 
@@ -506,12 +695,17 @@ __global__ __launch_bounds__(256, (TILES == 4 && NBR == 4 && S1 == 2) ? 3 : 2) v
         // lds1 was last read in iteration sp-1, which every wave left through a barrier
         if (sp + 1u < nsp) stage_super_panel(img + (size_t)(jsp + kSuper) * 8u, lds1, wave, lane);
         process(lds0, jsp);
+        publish();
         __syncthreads();  // (drains the in-flight global->LDS loads with vmcnt(0) first)
         if (sp + 1u >= nsp) break;
+        settle(false);
         if (sp + 2u < nsp) stage_super_panel(img + (size_t)(jsp + 2u * kSuper) * 8u, lds0, wave, lane);
         process(lds1, jsp + kSuper);
+        publish();
         __syncthreads();
+        if (sp + 2u < nsp) settle(false);
     }
+    settle(true);
     // every path leaves the loop through a barrier: all hits of this workgroup are in LDS now
     flush_pairs_wg(ctx, wave * 64u + lane);
 }
@@ -570,17 +764,22 @@ __global__ __launch_bounds__(256) void k_prefilter_probe(const uint4* __restrict
 // fast path's register allocation would have to keep clear.
 __global__ void k_set_hit_ctx(HitCtx* __restrict__ dst, const HitCtx src) { *dst = src; }
 
-// survivors among `pairs` sampled pairs -> form: the fetch form (id_rare) pays ~6 panel steps per surviving tile, the
-// register form (id_often) a flat ~5 %: switch when more than ~1 % of the (wave, panel) steps would see a survivor.
+// survivors among `pairs` sampled pairs -> form. The fetch form (id_rare) pays ~6 panel steps per surviving TILE: right when
+// survivors are real near-duplicates (uniform random hashes). The pair-queue form (id_mid) pays ~40 VALU instructions per
+// surviving tile and nothing on the matrix pipe: right for real frame hashes, whose first 128 bits agree within the tolerance
+// for ~2e-4 of unrelated pairs. The register form (id_often) pays one MFMA per surviving tile however many pairs survive in
+// it: right when most tiles hold several survivors (a library whose hashes barely differ in either half).
 __global__ void k_probe_decide(uint32_t* __restrict__ select, uint64_t pairs, uint32_t pairs_per_step, uint32_t id_rare,
-                               uint32_t id_often) {
+                               uint32_t id_mid, uint32_t id_often, float mid_max_per_tile) {
     // first the half: the one whose 128 bits let fewer unrelated pairs through (ties and near-ties stay with bits 0..127,
     // so that uniform data always runs the same configuration); then the form, from that half's rate
     const uint32_t lo = select[1], hi = select[2];
     const bool use_hi = (double)hi * 1.25 < (double)lo;
     select[3] = use_hi ? 1u : 0u;
     const double rate = pairs ? (double)(use_hi ? hi : lo) / (double)pairs : 0.0;
-    select[0] = rate * (double)pairs_per_step > 0.01 ? id_often : id_rare;
+    uint32_t form = id_rare;
+    if (rate * (double)pairs_per_step > 0.01) form = (id_mid != 0u && rate * 1024.0 <= (double)mid_max_per_tile) ? id_mid : id_often;
+    select[0] = form;
 }
 
 }  // namespace
@@ -607,6 +806,10 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
     return hipGetLastError();
 }
 
+// auto variant (13): the form for data with common false survivors (15 = pair queue; 0 = none, i.e. round 3's two-way choice)
+// and the survivor density (per 1024-pair tile, as the probe estimates it) up to which it is preferred over the register form
+uint32_t g_mfma_auto_mid = 15;
+uint32_t g_mfma_auto_mid_max_x100 = 200;
 uint32_t g_mfma_col_chunk_max = 8192;  // tuning knob (hvd_debug_set "mfma_col_chunk_max"); 2048..32768 within 3 %
 
 static uint32_t pick_col_chunk_m(uint32_t n_pad, uint32_t rows_per_wg) {
@@ -635,6 +838,7 @@ static bool mfma_form(int variant, MfmaForm* f) {
         case 11: *f = {4, 2, 2}; return true;
         case 12: *f = {4, 4, 2}; return true;
         case 14: *f = {8, 4, 2}; return true;  // experiment: register form with 8 tiles per wave (2 waves/SIMD)
+        case 15: *f = {8, 2, 2}; return true;  // pair-queue form: survivors settled pair by pair on the VALU
         default: return false;
     }
 }
@@ -647,7 +851,8 @@ bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, u
     return true;
 }
 
-static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32_t* d_group_t, int s1) {
+static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32_t* d_group_t, int s1, const void* d_img_q,
+                      const void* d_img_t) {
     HitCtx c;
     c.group = a.d_group;
     c.group_t = d_group_t;
@@ -661,11 +866,19 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
     c.inv_scale2 = 1.0f / fp4_scale2();
     c.rect = rect ? 1u : 0u;
     c.acc_start = fp4_scale2() * ((float)(64 * s1) - 2.0f * (float)a.max_dist - 1.0f);
+    c.img_q = (const uint4*)d_img_q;
+    c.img_t = (const uint4*)d_img_t;
+    c.db_t = (const uint4*)a.d_db;
+    c.db_q = (const uint4*)(rect ? a.d_db_q : a.d_db);
+    if (c.db_q == nullptr || c.db_t == nullptr) c.db_q = c.db_t = nullptr;
+    c.max_dist = a.max_dist;
+    uint32_t* sel = nullptr;
+    c.qstats = mfma_select_buffer(&sel) == hipSuccess ? reinterpret_cast<unsigned long long*>(sel + 128) : nullptr;
     return c;
 }
 
 // One launch of one form. rect: rows = the nq hashes of d_img_q, columns = the a.n hashes of d_img.
-template <int T, int NBR, int S1>
+template <int T, int NBR, int S1, bool QUEUE = false>
 static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q, uint32_t nq,
                               const int32_t* d_group_t, const uint32_t* d_select, uint32_t select_id, hipStream_t s) {
     const uint32_t n_pad = fp4_rows_padded(a.n);
@@ -688,13 +901,13 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
     hipError_t e = mfma_select_buffer(&buf);
     if (e != hipSuccess) return e;
     HitCtx* ctx = reinterpret_cast<HitCtx*>(buf + 16);
-    hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1));
+    hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1, rect ? d_img_q : d_img, d_img));
     if (rect)
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
                            select_id);
     else
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)nullptr, fp4_scale2(), ctx, d_select,
                            select_id);
     return hipGetLastError();
@@ -709,6 +922,7 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
         case 11: return launch_form<4, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 11u, s);
         case 12: return launch_form<4, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 12u, s);
         case 14: return launch_form<8, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 14u, s);
+        case 15: return launch_form<8, 2, 2, true>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 15u, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -724,8 +938,17 @@ static std::mutex g_launch_mu;
 hipError_t mfma_select_buffer(uint32_t** out) {
     if (!g_select) {
         static_assert(sizeof(HitCtx) <= 192, "hit context does not fit its slot");
-        hipError_t e = hipMalloc((void**)&g_select, 256);  // 16 B of select words, the hit context at +64
-        if (e != hipSuccess) return e;
+        // 16 B of select words, the hit context at +64, 16 counters of HVD_K2_QSTATS builds at +512
+        hipError_t e = hipMalloc((void**)&g_select, 1024);
+        // (hipMemset on device memory does not wait: without the synchronisation it can land on top of the first context
+        // that the non-blocking library stream writes)
+        if (e == hipSuccess) e = hipMemset(g_select, 0, 1024);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            if (g_select) (void)hipFree(g_select);
+            g_select = nullptr;
+            return e;
+        }
     }
     *out = g_select;
     return hipSuccess;
@@ -750,16 +973,21 @@ static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rec
     const uint32_t rows = nrows < kProbeRows ? nrows : kProbeRows, cols = a.n < kProbeCols ? a.n : kProbeCols;
     hipLaunchKernelGGL(k_prefilter_probe, dim3((rows + 255u) / 256u, (cols + 255u) / 256u), dim3(256), 0, s,
                        (const uint4*)(rect ? d_img_q : d_img), nrows, (const uint4*)d_img, a.n, a.max_dist, sel);
-    hipLaunchKernelGGL(k_probe_decide, dim3(1), dim3(1), 0, s, sel, (uint64_t)rows * cols, 8192u, 9u, 12u);
+    hipLaunchKernelGGL(k_probe_decide, dim3(1), dim3(1), 0, s, sel, (uint64_t)rows * cols, 8192u, 9u, g_mfma_auto_mid, 12u,
+                       0.01f * (float)g_mfma_auto_mid_max_x100);
     e = launch_variant(9, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
     if (e != hipSuccess) return e;
+    if (g_mfma_auto_mid) {
+        e = launch_variant((int)g_mfma_auto_mid, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
+        if (e != hipSuccess) return e;
+    }
     return launch_variant(12, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
 }
 
 static int effective_variant(int variant, uint32_t max_dist) {
     // the 128-bit first stage needs 128 - 2*max_dist > 0
     if (max_dist >= 64u) {
-        if (variant == 9 || variant == 13) return 8;
+        if (variant == 9 || variant == 13 || variant == 15) return 8;
         if (variant == 11 || variant == 12) return 10;
         if (variant == 14) return 8;
     }

@@ -94,12 +94,18 @@ __device__ __forceinline__ float wave_sum_f32(float v) {  // exact: integer-valu
     return v;
 }
 
-// The DCT matrix as compile-time constants (scripts/gen_dct_table.py; hvd_init refuses to start if the host's own
-// computation of the matrix differs from this table).
+// The DCT matrix as compile-time constants (scripts/gen_dct_table.py). This table is authoritative: hvd_init does not
+// consult the host's libm (tests/ compare the table with hvd_dct_matrix_libm() and with the oracle).
 constexpr uint32_t kDctBits[16][64] = {
 #include "dct_table.inc"
 };
 __device__ __forceinline__ constexpr float dct_lit(int i, int k) { return __builtin_bit_cast(float, kDctBits[i][k]); }
+
+__device__ __forceinline__ void wave_lds_handover() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // KIND 0: uint8 gray 64x64 frames. KIND 1: float 64x64 buffers (down-sampler output).
 // DLDS: where stage 1 takes D[i][k] from. 0: scalar loads (SGPR operands: v_mul_f32 s,v issues at half rate,
@@ -242,7 +248,10 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
             }
             if (lane == 0) quality[f] = qual;
         }
-        __syncthreads();  // T visible to the whole wave (cross-lane through LDS)
+        // T[wave] is private to this wave: wave-scope ordering is all the hand-over needs (LDS operations of one wave
+        // execute in order), so the four waves of a workgroup -- four independent frames -- never wait for each other
+        // (round 4; two workgroup barriers per frame cost ~0.35 of the launch at 10 k frames)
+        wave_lds_handover();
 
         if (valid) {
             // ---- stage 2: B[i][j] = sum_k T[i][k] * D[j][k], k ascending ------------
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
                 reinterpret_cast<unsigned long long*>(hashes)[f * 4 + lane] = w;
             }
         }
-        __syncthreads();  // T is rewritten by the next trip
+        wave_lds_handover();  // T[wave] is rewritten by this wave's next trip
       }
         if (work == nullptr) {  // short launches stride statically: a thousand workgroups drawing at once wait on each other
             ck += gridDim.x;
