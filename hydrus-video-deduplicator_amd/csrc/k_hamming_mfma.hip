@@ -100,6 +100,24 @@ __device__ __forceinline__ int or16_bits(const v16f& c) {
     return m0 | m3;
 }
 
+// The same tree, keeping its six first-level results: group g < 5 = registers 3g..3g+2, group 5 = register 15. The pair-queue
+// form tells WHICH registers of a lane hold a survivor from these (6 sign bits) instead of from the 16 accumulators.
+struct Or16Groups {
+    int g[6];
+    int all;
+};
+__device__ __forceinline__ Or16Groups or16_groups(const v16f& c) {
+    Or16Groups o;
+    o.g[0] = __float_as_int(c[0]) | __float_as_int(c[1]) | __float_as_int(c[2]);
+    o.g[1] = __float_as_int(c[3]) | __float_as_int(c[4]) | __float_as_int(c[5]);
+    o.g[2] = __float_as_int(c[6]) | __float_as_int(c[7]) | __float_as_int(c[8]);
+    o.g[3] = __float_as_int(c[9]) | __float_as_int(c[10]) | __float_as_int(c[11]);
+    o.g[4] = __float_as_int(c[12]) | __float_as_int(c[13]) | __float_as_int(c[14]);
+    o.g[5] = __float_as_int(c[15]);
+    o.all = (o.g[0] | o.g[1] | o.g[2]) | (o.g[3] | o.g[4] | o.g[5]);
+    return o;
+}
+
 __device__ __forceinline__ float min16(const v16f& c) {
     float m0 = fminf(fminf(c[0], c[1]), c[2]);
     float m1 = fminf(fminf(c[3], c[4]), c[5]);
@@ -351,33 +369,78 @@ __device__ __noinline__ void panel_survivors(uint32_t marks, const uint4* __rest
 // three siblings run into the next barrier and wait for it (first version: SQ_WAIT_ANY +50 %, matrix pipe 0.50 busy). Behind
 // a barrier everybody is in step anyway; 256 lanes take one entry each, one round trip, every ~7 super-panels.
 constexpr uint32_t kQTileLanes = 4;   // a tile with survivors in more lanes (columns x halves) than this takes the tile route (4e-4 of the surviving tiles of frame hashes)
-constexpr uint32_t kQWaveCap = 256;   // entries per wave
 constexpr uint32_t kQSuperMax = (kSuper / 32) * 8 * kQTileLanes;  // most that one wave can add between two barriers
-constexpr uint32_t kQDrainAt = 192;   // settle when the workgroup holds this many (or a wave could overflow before the next barrier)
-// entry: x = survivor mask of the lane's 16 accumulator registers (bit 15 - r <-> register r) | (first row of the lane,
-// relative to the workgroup's first row: wave * rows per wave + 32 t + 4 h) << 16; y = column (absolute)
+constexpr uint32_t kQWaveCap = 256 + kQSuperMax;                  // entries per wave
+constexpr uint32_t kQDrainAt = 768;   // settle when the workgroup holds this many (or a wave could overflow before the next barrier)
+// entry: x = group mask of the lane's accumulator registers (bit 5 - g <-> a survivor among the registers of group g, see
+// or16_groups) | (first row of the tile, relative to the workgroup's first row: wave * rows per wave + 32 t) << 16;
+// y = column (absolute) << 1 | h (the lane's half: its rows start 4 h below the tile's first) -- hence n_pad < 2^31
 __shared__ uint2 g_wave_queue[4][kQWaveCap];
 __shared__ __attribute__((aligned(16))) uint32_t g_wave_qn[4];
 
 __device__ __forceinline__ uint32_t sign_popc(const uint4& x, const uint4& y, uint32_t acc) {
-    // equal magnitude bits cancel: only sign nibbles survive the XOR (rows beyond n are FP4 zeros -- filtered by index)
+    // FP4 images: equal magnitude bits cancel, only sign nibbles survive the XOR (rows beyond n are FP4 zeros -- filtered
+    // by index); packed hashes: the plain Hamming distance
     return acc + __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
 }
 
+// One candidate pair, all 256 bits, all checks, both sinks (rare: what the drain's filter lets through).
+__device__ __noinline__ void settle_pair(const HitCtx* __restrict__ ctx, uint32_t i, uint32_t j) {
+    const HitCtx c = load_ctx(ctx);
+    const bool rect = c.rect != 0u;
+    if (!(j < c.n && (rect ? i < c.nq : i < j))) return;
+    uint32_t d = 0;
+    if (c.db_t != nullptr) {  // launch-uniform
+        const uint4 x0 = c.db_q[(size_t)i * 2u], x1 = c.db_q[(size_t)i * 2u + 1u];
+        const uint4 y0 = c.db_t[(size_t)j * 2u], y1 = c.db_t[(size_t)j * 2u + 1u];
+        d = sign_popc(x0, y0, sign_popc(x1, y1, 0u));
+    } else {
+        const uint4* __restrict__ pi = c.img_q + (size_t)i * 8u;
+        const uint4* __restrict__ pj = c.img_t + (size_t)j * 8u;
+        const uint32_t si = (i >> 1) & 7u, sj = (j >> 1) & 7u;
+#pragma unroll 1
+        for (uint32_t c0 = 0; c0 < 8u; c0 += 4u) {
+#pragma unroll
+            for (uint32_t ch = c0; ch < c0 + 4u; ++ch) d = sign_popc(pi[ch ^ si], pj[ch ^ sj], d);
+        }
+    }
+    if (d > c.max_dist) return;
+    if (c.group != nullptr && c.group[i] == (rect ? c.group_t[j] : c.group[j])) return;
+    if (c.vs.set == nullptr) {
+        append_pair_wg(c.out, c.cap, c.count, i, j, d);
+    } else {
+        hvd::sink_insert(c.vs, hvd::vkey_make(0u, i, (uint32_t)c.vs.vid_t[j]));
+        hvd::sink_insert(c.vs, hvd::vkey_make(rect ? 1u : 0u, j, (uint32_t)c.vs.vid_q[i]));
+    }
+}
+
 // Settle all four queues (n0..n3 entries). Called by all 256 threads behind a barrier; the caller puts another barrier
-// behind it before anybody pushes again.
+// behind it before anybody pushes again. Two entries per thread and round, their loads issued together: the cost of a
+// settlement is its memory round trips (the packed hashes are touched by nobody else: the loads miss L2), not its work.
+// With packed hashes the first look is at the 128 bits the first stage did NOT see (other_half: 0 = bits 0..127): 16 B per
+// hash, and of unrelated pairs that agreed in one half, 2e-4 agree in the other; those go on to settle_pair.
 __device__ __noinline__ void drain_queues_wg(const HitCtx* __restrict__ ctx, uint32_t n0_v, uint32_t n1_v, uint32_t n2_v,
-                                             uint32_t n3_v, uint32_t row0_v, uint32_t tid) {
+                                             uint32_t n3_v, uint32_t row0_v, uint32_t other_half_v, uint32_t tid) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0_v), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1_v);
     const uint32_t n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n2_v), n3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n3_v);
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
+    const uint32_t oh = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
 #else
-    const uint32_t n0 = n0_v, n1 = n1_v, n2 = n2_v, n3 = n3_v, row0 = row0_v;
+    const uint32_t n0 = n0_v, n1 = n1_v, n2 = n2_v, n3 = n3_v, row0 = row0_v, oh = other_half_v;
 #endif
-    const HitCtx c = load_ctx(ctx);
-    const bool rect = c.rect != 0u;
+    // (only what the filter needs is fetched here -- the full context is settle_pair's business: this function's register
+    // footprint is what the kernel has to keep clear of across the call)
     const uint32_t total = n0 + n1 + n2 + n3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto* cc = (const __attribute__((address_space(4))) HitCtx*)uniform_u64((unsigned long long)ctx);
+#else
+    const HitCtx* cc = ctx;
+#endif
+    const uint4* __restrict__ db_q = cc->db_q;
+    const uint4* __restrict__ db_t = cc->db_t;
+    const uint32_t max_dist = cc->max_dist;
+    const bool packed = db_t != nullptr;
 #pragma unroll 1
     for (uint32_t k0 = 0; k0 < total; k0 += 256u) {
         const uint32_t k = k0 + tid;
@@ -385,38 +448,28 @@ __device__ __noinline__ void drain_queues_wg(const HitCtx* __restrict__ ctx, uin
         const uint32_t w = k < n0 ? 0u : k < n0 + n1 ? 1u : k < n0 + n1 + n2 ? 2u : 3u;
         const uint32_t idx = k - (w == 0u ? 0u : w == 1u ? n0 : w == 2u ? n0 + n1 : n0 + n1 + n2);
         const uint2 e = g_wave_queue[w][idx];
-        uint32_t m = e.x & 0xFFFFu;
-        const uint32_t ib = row0 + (e.x >> 16), j = e.y;
-        const int32_t gcol = c.group != nullptr && j < c.n ? (rect ? c.group_t[j] : c.group[j]) : 0;
+        uint32_t gm = e.x & 63u;
+        const uint32_t ib = row0 + (e.x >> 16) + 4u * (e.y & 1u), j = e.y >> 1;
 #pragma unroll 1
-        while (m != 0u) {
-            const uint32_t bit = 31u - (uint32_t)__clz((int)m);
-            m &= ~(1u << bit);
-            const uint32_t r = 15u - bit;
-            const uint32_t i = ib + (r & 3u) + 8u * (r >> 2);
-            uint32_t d = 0;
-            if (c.db_t != nullptr) {  // launch-uniform
-                const uint4 x0 = c.db_q[(size_t)i * 2u], x1 = c.db_q[(size_t)i * 2u + 1u];
-                const uint4 y0 = c.db_t[(size_t)j * 2u], y1 = c.db_t[(size_t)j * 2u + 1u];
-                d = sign_popc(x0, y0, sign_popc(x1, y1, 0u));
-            } else {
-                const uint4* __restrict__ pi = c.img_q + (size_t)i * 8u;
-                const uint4* __restrict__ pj = c.img_t + (size_t)j * 8u;
-                const uint32_t si = (i >> 1) & 7u, sj = (j >> 1) & 7u;
-#pragma unroll 1
-                for (uint32_t c0 = 0; c0 < 8u; c0 += 4u) {
-#pragma unroll
-                    for (uint32_t ch = c0; ch < c0 + 4u; ++ch) d = sign_popc(pi[ch ^ si], pj[ch ^ sj], d);
-                }
+        while (gm != 0u) {  // one round per set group bit: almost always one
+            const uint32_t bit = 31u - (uint32_t)__clz((int)gm);
+            gm &= ~(1u << bit);
+            const uint32_t g = 5u - bit, r0 = 3u * g, nr = g == 5u ? 1u : 3u;  // registers r0 .. r0 + nr - 1
+            const uint32_t i0 = ib + (r0 & 3u) + 8u * (r0 >> 2);
+            const uint32_t r1 = r0 + (nr > 1u ? 1u : 0u), r2 = r0 + (nr > 1u ? 2u : 0u);
+            const uint32_t i1 = ib + (r1 & 3u) + 8u * (r1 >> 2), i2 = ib + (r2 & 3u) + 8u * (r2 >> 2);
+            uint32_t pass = nr == 1u ? 1u : 7u;
+            if (packed) {
+                const uint4 col = db_t[(size_t)j * 2u + oh];
+                const uint4 x0 = db_q[(size_t)i0 * 2u + oh], x1 = db_q[(size_t)i1 * 2u + oh], x2 = db_q[(size_t)i2 * 2u + oh];
+                pass &= (sign_popc(x0, col, 0u) <= max_dist ? 1u : 0u) | (sign_popc(x1, col, 0u) <= max_dist ? 2u : 0u) |
+                        (sign_popc(x2, col, 0u) <= max_dist ? 4u : 0u);
             }
-            bool ok = d <= c.max_dist && j < c.n && (rect ? i < c.nq : i < j);
-            if (ok && c.group != nullptr) ok = c.group[i] != gcol;
-            if (!ok) continue;
-            if (c.vs.set == nullptr) {
-                append_pair_wg(c.out, c.cap, c.count, i, j, d);
-            } else {
-                hvd::sink_insert(c.vs, hvd::vkey_make(0u, i, (uint32_t)c.vs.vid_t[j]));
-                hvd::sink_insert(c.vs, hvd::vkey_make(rect ? 1u : 0u, j, (uint32_t)c.vs.vid_q[i]));
+#pragma unroll 1
+            while (pass != 0u) {  // rare with packed hashes (2e-4 of the candidates)
+                const uint32_t q = (uint32_t)__ffs((int)pass) - 1u;
+                pass &= pass - 1u;
+                settle_pair(ctx, q == 0u ? i0 : q == 1u ? i1 : i2, j);
             }
         }
     }
@@ -526,6 +579,7 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
 
     const v16f zero = {c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1};  // the accumulators' start value
     uint32_t qn = 0;  // QUEUE: entries waiting in this wave's pair queue (wave-uniform)
+    const uint32_t qcol = (li << 1) | h;  // QUEUE: this lane's share of an entry's y word: (column << 1) | h
 
     // The two LDS buffers are separate objects and the super-panel loop is unrolled by two, so that every
     // ds_read names one array and every in-flight global->LDS load the other: with one two-dimensional array
@@ -552,47 +606,28 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
                 // Each tile is judged while its accumulators are live; a surviving tile hands its few surviving PAIRS to the
                 // wave's queue (or, when there are many, its index to the tile route) and the matrix pipe moves on.
                 uint32_t tmarks = 0;  // wave-uniform: bit (TILES-1-t) <-> tile t takes the tile route
-                auto note = [&](const int t, const v16f& acc) {
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 1  // timing-only ablations (wrong results): 1 = a surviving tile is ignored
+                auto note = [&](const int t, const Or16Groups& o) {
+                    // ~13 VALU instructions: this kernel has ~10 VALU issue slots to spare per tile and a fifth of all tiles
+                    // of a frame-hash library come here, so every instruction of this path is on the clock. Which registers
+                    // of a lane hold the survivor is taken from the OR tree's six first-level results, not from the 16
+                    // accumulators (round 4: -11 instructions; the drain looks at up to three rows per entry instead).
+                    uint32_t gm = (uint32_t)o.g[0] >> 31;  // bit (5 - g) <-> group g
+#pragma unroll
+                    for (int g = 1; g < 6; ++g) gm = __builtin_amdgcn_alignbit(gm, (uint32_t)o.g[g], 31);
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 2  // timing-only ablation (wrong results): the mask is built, nothing is pushed
+                    asm volatile("" ::"v"(gm));
                     return;
 #endif
-                    // ~22 VALU instructions: this kernel has ~10 VALU issue slots to spare per tile and a fifth of all tiles
-                    // of a frame-hash library come here, so every instruction of this path is on the clock
-                    uint32_t ma = 0, mb = 0;  // two independent chains; bit (15 - r) of the result <-> accumulator register r
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 4  // 4 = a 6-bit mask instead of 16 bits (what a group mask would cost)
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-#else
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-#endif
-                        if (kSign) {
-                            ma = __builtin_amdgcn_alignbit(ma, (uint32_t)__float_as_int(acc[r]), 31);
-                            mb = __builtin_amdgcn_alignbit(mb, (uint32_t)__float_as_int(acc[r + 8]), 31);
-                        } else {
-                            ma = (ma << 1) | (__float_as_int(acc[r]) >= thr1_bits ? 1u : 0u);
-                            mb = (mb << 1) | (__float_as_int(acc[r + 8]) >= thr1_bits ? 1u : 0u);
-                        }
-                    }
-                    const uint32_t m = (ma << 8) | mb;
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 2  // 2 = the mask is built, nothing is pushed
-                    asm volatile("" ::"v"(m));
-                    return;
-#endif
-                    const unsigned long long act = __ballot(m != 0u);
+                    const unsigned long long act = __ballot(gm != 0u);
                     // (two 32-bit counts: with the 64-bit one the compare below lands on the VALU)
                     const uint32_t nl = (uint32_t)__builtin_popcount((uint32_t)act) + (uint32_t)__builtin_popcount((uint32_t)(act >> 32));
 #ifdef HVD_K2_QSTATS
                     {
                         const HitCtx cs = load_ctx(ctx);
-                        uint32_t tot = __popc(m);
-                        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off);
                         if (lane == 0u) {
                             atomicAdd(&cs.qstats[0], 1ull);
-                            atomicAdd(&cs.qstats[3], (unsigned long long)tot);
+                            atomicAdd(&cs.qstats[3], (unsigned long long)nl);
                             if (nl > kQTileLanes) atomicAdd(&cs.qstats[1], 1ull);
-                            const uint32_t b = tot <= 1 ? 8 : tot <= 2 ? 9 : tot <= 4 ? 10 : tot <= 8 ? 11 : tot <= 16 ? 12 : tot <= 32 ? 13 : tot <= 64 ? 14 : 15;
-                            atomicAdd(&cs.qstats[b], 1ull);
                         }
                     }
 #endif
@@ -600,20 +635,43 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
                         tmarks |= 1u << (TILES - 1 - t);
                         return;
                     }
-                    if (m != 0u) {
+                    if (gm != 0u) {
                         const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-                        g_wave_queue[wave][slot] = make_uint2(m | ((wave * WROWS + 32u * (uint32_t)t + 4u * h) << 16), jsp + cl);
+                        // x: wave-uniform but for the mask (one v_or with an SGPR); the lane's half h rides in bit 0 of y, next to
+                        // the column, whose lane-constant part is a register the loop holds anyway (a per-lane row offset here
+                        // cost a register that the allocator spilled: a scratch reload -- and its vmcnt(0), which also waits
+                        // for the panel prefetch -- in every note)
+                        g_wave_queue[wave][slot] = make_uint2(gm | ((wave * WROWS + 32u * (uint32_t)t) << 16), ((jsp + 32u * p) << 1) + qcol);
                     }
                     qn += nl;
+                };
+                static_assert(kSign, "the pair-queue form reads sign bits (HVD_K2_SIGN=1)");
+                auto hit = [&](const Or16Groups& o) { return __any(o.all < 0); };
+                // A VALU read of a register an MFMA is still writing is a SOFTWARE-managed hazard on gfx950 (the compiler
+                // normally inserts s_nop wait states). Here hipcc 7.2's scheduler moved the first two v_or3 of a tile's tree
+                // in front of the NEXT tile's MFMAs, into a basic block with several predecessors right behind the judged
+                // tile's in-place MFMA, and its hazard recogniser lost track: half-written accumulators were read and 0.4 %
+                // of the planted pairs went missing (scripts/gpu_k2_missing.py: all in tile 1, registers 2, 4, 5). The order
+                // is therefore pinned: both MFMAs of tile t+1 are ISSUED before anything of tile t's tree -- the second of
+                // them depends on the first, which cannot start before tile t's last MFMA has left the in-order pipe, so
+                // the tree reads finished registers whatever the recogniser counts. (An explicit s_nop 11 in front of every
+                // tree is also correct, but comes on top of the compiler's own waits: +5 % on uniform data.)
+                auto judge = [&](const v16f& acc) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    return or16_groups(acc);
                 };
                 v16f cur = tile_dot<0, S1>(a[0], b, zero);
 #pragma unroll
                 for (int t = 1; t < TILES; ++t) {
                     const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
-                    if (__builtin_expect(stage1_hit(cur), 0)) note(t - 1, cur);
+                    const Or16Groups o = judge(cur);
+                    if (__builtin_expect(hit(o), 0)) note(t - 1, o);
                     cur = nxt;
                 }
-                if (__builtin_expect(stage1_hit(cur), 0)) note(TILES - 1, cur);
+                {
+                    const Or16Groups o = judge(cur);
+                    if (__builtin_expect(hit(o), 0)) note(TILES - 1, o);
+                }
                 // (both calls sit where no accumulator is live: the handlers' registers add to the live set across a call)
                 if (__builtin_expect(tmarks != 0u, 0)) panel_survivors<TILES>(tmarks, imgq, panel, wrow0, jsp + 32u * p, lane, ctx);
             } else if constexpr (NBR == 2) {
@@ -679,7 +737,7 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
             const uint32_t sum = n0 + n1 + n2 + n3, mx = max(max(n0, n1), max(n2, n3));
             if (final ? sum != 0u : (sum >= kQDrainAt || mx > kQWaveCap - kQSuperMax)) {
 #if !(defined(HVD_K2_QABL) && HVD_K2_QABL == 3)  // 3 = pushed entries are dropped instead of settled
-                drain_queues_wg(ctx, n0, n1, n2, n3, row0, wave * 64u + lane);
+                drain_queues_wg(ctx, n0, n1, n2, n3, row0, selx ? 0u : 1u, wave * 64u + lane);
 #endif
                 qn = 0;
                 __syncthreads();  // nobody pushes (or publishes) again before everybody has read the queues
@@ -973,18 +1031,21 @@ static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rec
     const uint32_t rows = nrows < kProbeRows ? nrows : kProbeRows, cols = a.n < kProbeCols ? a.n : kProbeCols;
     hipLaunchKernelGGL(k_prefilter_probe, dim3((rows + 255u) / 256u, (cols + 255u) / 256u), dim3(256), 0, s,
                        (const uint4*)(rect ? d_img_q : d_img), nrows, (const uint4*)d_img, a.n, a.max_dist, sel);
-    hipLaunchKernelGGL(k_probe_decide, dim3(1), dim3(1), 0, s, sel, (uint64_t)rows * cols, 8192u, 9u, g_mfma_auto_mid, 12u,
+    // (the pair queue keeps (column << 1 | half) in 32 bits)
+    const uint32_t mid = fp4_rows_padded(a.n) < (1u << 31) ? g_mfma_auto_mid : 0u;
+    hipLaunchKernelGGL(k_probe_decide, dim3(1), dim3(1), 0, s, sel, (uint64_t)rows * cols, 8192u, 9u, mid, 12u,
                        0.01f * (float)g_mfma_auto_mid_max_x100);
     e = launch_variant(9, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
     if (e != hipSuccess) return e;
-    if (g_mfma_auto_mid) {
-        e = launch_variant((int)g_mfma_auto_mid, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
+    if (mid) {
+        e = launch_variant((int)mid, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
         if (e != hipSuccess) return e;
     }
     return launch_variant(12, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
 }
 
-static int effective_variant(int variant, uint32_t max_dist) {
+static int effective_variant(int variant, uint32_t max_dist, uint32_t n) {
+    if (variant == 15 && fp4_rows_padded(n) >= (1u << 31)) variant = 12;  // the pair queue keeps (column << 1 | half) in 32 bits
     // the 128-bit first stage needs 128 - 2*max_dist > 0
     if (max_dist >= 64u) {
         if (variant == 9 || variant == 13 || variant == 15) return 8;
@@ -999,7 +1060,7 @@ hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_
     if (nq == 0 || a.n == 0) return hipSuccess;
     std::lock_guard<std::mutex> lk(g_launch_mu);
     if (a.max_dist >= 128u) return hipErrorInvalidValue;  // sign trick needs a positive threshold
-    const int v = effective_variant(a.variant, a.max_dist);
+    const int v = effective_variant(a.variant, a.max_dist, a.n);
     if (v == 13) return launch_auto(a, d_img_t, true, d_img_q, nq, d_group_t, s);
     return launch_variant(v, a, d_img_t, true, d_img_q, nq, d_group_t, nullptr, s);
 }
@@ -1015,7 +1076,7 @@ hipError_t launch_allpairs_mfma(const AllPairsArgs& a_in, const void* d_img, hip
         a.variant = 0;
         return launch_allpairs(a, s);
     }
-    const int v = effective_variant(a.variant, a.max_dist);
+    const int v = effective_variant(a.variant, a.max_dist, a.n);
     std::lock_guard<std::mutex> lk(g_launch_mu);
     if (v == 13) return launch_auto(a, d_img, false, nullptr, 0u, nullptr, s);
     return launch_variant(v, a, d_img, false, nullptr, 0u, nullptr, nullptr, s);
