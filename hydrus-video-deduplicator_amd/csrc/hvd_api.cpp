@@ -72,7 +72,7 @@ struct Ctx {
     // allocated or freed per call once the sizes have been seen (h_mu serialises the users)
     enum Scr {
         S_DB, S_IMG, S_GRP, S_PAIRS, S_DB2, S_IMG2, S_GRP2, S_VIDQ, S_VIDT, S_OFF, S_SET, S_SET2, S_PKEYS, S_PCNT, S_LIST,
-        S_LISTALL, S_VOUT, S_FRAMES, S_FSCR, S_HASH, S_QUAL, S_COMPACT, S_COUNTERS, S_N
+        S_LISTALL, S_VOUT, S_FRAMES, S_FSCR, S_HASH, S_QUAL, S_COMPACT, S_COUNTERS, S_BITS, S_BITS2, S_N
     };
     void* scr[S_N] = {};
     size_t scr_cap[S_N] = {};
@@ -366,6 +366,10 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_mfma_auto_mid = (uint32_t)value;
         return HVD_OK;
     }
+    if (strcmp(key, "mfma_queue_packed") == 0) {  // 0: the pair-queue form settles its candidates from the FP4 images only
+        hvd::g_mfma_queue_packed = value != 0;
+        return HVD_OK;
+    }
     if (strcmp(key, "mfma_auto_mid_max_x100") == 0) {  // ... up to this many survivors per 1024-pair tile (x 0.01)
         if (value < 0) return fail(HVD_ERR_ARG, "mfma_auto_mid_max_x100 must not be negative");
         hvd::g_mfma_auto_mid_max_x100 = (uint32_t)value;
@@ -574,8 +578,18 @@ int hvd_dev_cross_hamming256_mfma(const void* d_img_q, int64_t nq, const void* d
     if ((d_group_q == nullptr) != (d_group_t == nullptr)) return fail(HVD_ERR_ARG, "pass both group maps or neither");
     if (nq == 0 || nt == 0) return HVD_OK;
     if (!d_img_q || !d_img_t) return fail(HVD_ERR_ARG, "NULL image");
+    // packed hashes for the pair-queue form, derived from the images into the pool (this entry is handed images only)
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+    void *d_bits_t = nullptr, *d_bits_q = nullptr;
+    if (int rc = grow(&g.scr[Ctx::S_BITS], &g.scr_cap[Ctx::S_BITS], 32 * (size_t)nt)) return rc;
+    if (int rc = grow(&g.scr[Ctx::S_BITS2], &g.scr_cap[Ctx::S_BITS2], 32 * (size_t)nq)) return rc;
+    d_bits_t = g.scr[Ctx::S_BITS];
+    d_bits_q = g.scr[Ctx::S_BITS2];
+    HIP_TRY(hvd::launch_pack_fp4(d_img_t, (uint32_t)nt, d_bits_t, g.stream));
+    HIP_TRY(hvd::launch_pack_fp4(d_img_q, (uint32_t)nq, d_bits_q, g.stream));
     hvd::AllPairsArgs a;
-    a.d_db = nullptr;
+    a.d_db = d_bits_t;
+    a.d_db_q = d_bits_q;
     a.n = (uint32_t)nt;
     a.d_group = (const int32_t*)d_group_q;
     a.max_dist = (uint32_t)max_dist;
@@ -845,6 +859,14 @@ int vmatch_build(const VmArgs& v) {
     unsigned long long c[4] = {0, 0, 0, 0};
     auto local = [&]() -> int {
     SCR(S_COUNTERS, 64, d_counters);
+    // the pair-queue form of the all-pairs kernel settles its candidates on PACKED hashes; this entry is handed images only
+    void *d_bits_t = nullptr, *d_bits_q = nullptr;
+    SCR(S_BITS, 32 * (size_t)v.nt, d_bits_t);
+    HIP_TRY(hvd::launch_pack_fp4(v.d_img_t, v.nt, d_bits_t, g.stream));
+    if (v.rect) {
+        SCR(S_BITS2, 32 * (size_t)v.nq, d_bits_q);
+        HIP_TRY(hvd::launch_pack_fp4(v.d_img_q, v.nq, d_bits_q, g.stream));
+    }
     const unsigned long long frames = (unsigned long long)v.nt + (v.rect ? v.nq : 0u);
     slots = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * frames));
     if (g.v_force_slots_log2) slots = 1ull << g.v_force_slots_log2;
@@ -854,7 +876,8 @@ int vmatch_build(const VmArgs& v) {
         HIP_TRY(hipMemsetAsync(d_set, 0xFF, 8 * slots, g.stream));
         HIP_TRY(hipMemsetAsync(d_counters, 0, 32, g.stream));
         hvd::AllPairsArgs a;
-        a.d_db = nullptr;
+        a.d_db = d_bits_t;
+        a.d_db_q = d_bits_q;
         a.n = v.nt;
         a.d_group = v.rect ? v.d_excl_q : v.d_vid_q;  // symmetric: frames of one video never match each other
         a.max_dist = (uint32_t)v.max_dist;

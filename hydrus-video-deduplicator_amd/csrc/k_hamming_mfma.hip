@@ -68,6 +68,23 @@ __global__ __launch_bounds__(256) void k_expand_fp4(const uint32_t* __restrict__
     img[(size_t)hash * 8u + img_slot(hash, chunk)] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// The inverse: the packed 32-byte hashes of an FP4 image (one thread per (hash, chunk): 32 sign nibbles -> 32 bits). The
+// pair-queue form settles its candidates on packed hashes (16 B per half instead of 64); callers that hand the library
+// only images (video search, cross search) get them derived here. Rows >= n are not written.
+__global__ __launch_bounds__(256) void k_pack_fp4(const uint4* __restrict__ img, uint32_t n, uint32_t* __restrict__ db) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (uint64_t)n * 8u) return;
+    const uint32_t hash = (uint32_t)(idx >> 3), chunk = (uint32_t)(idx & 7u);
+    const uint4 v = img[(size_t)hash * 8u + img_slot(hash, chunk)];
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w |= ((d[k] >> (4 * t + 3)) & 1u) << (8 * k + t);
+    db[(size_t)hash * 8u + chunk] = w;
+}
+
 // Max of the 16 accumulator registers, taken on the BIT PATTERNS as signed integers:
 // for a positive threshold, "float >= thr" and "bits >= thr_bits" agree (negative floats
 // have the sign bit set and compare below every positive pattern), and v_max3_i32 needs no
@@ -371,9 +388,9 @@ __device__ __noinline__ void panel_survivors(uint32_t marks, const uint4* __rest
 constexpr uint32_t kQTileLanes = 4;   // a tile with survivors in more lanes (columns x halves) than this takes the tile route (4e-4 of the surviving tiles of frame hashes)
 constexpr uint32_t kQSuperMax = (kSuper / 32) * 8 * kQTileLanes;  // most that one wave can add between two barriers
 constexpr uint32_t kQWaveCap = 256 + kQSuperMax;                  // entries per wave
-constexpr uint32_t kQDrainAt = 768;   // settle when the workgroup holds this many (or a wave could overflow before the next barrier)
+constexpr uint32_t kQDrainAt = 700;   // settle when the workgroup holds this many: one round of drain_queues_wg (3 x 256) with the next super-panel's ~30 on top
 // entry: x = group mask of the lane's accumulator registers (bit 5 - g <-> a survivor among the registers of group g, see
-// or16_groups) | (first row of the tile, relative to the workgroup's first row: wave * rows per wave + 32 t) << 16;
+// or16_groups) | (first row of the tile, relative to the WAVE's first row: 32 t) << 16 (the wave is the queue's index);
 // y = column (absolute) << 1 | h (the lane's half: its rows start 4 h below the tile's first) -- hence n_pad < 2^31
 __shared__ uint2 g_wave_queue[4][kQWaveCap];
 __shared__ __attribute__((aligned(16))) uint32_t g_wave_qn[4];
@@ -384,9 +401,11 @@ __device__ __forceinline__ uint32_t sign_popc(const uint4& x, const uint4& y, ui
     return acc + __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
 }
 
-// One candidate pair, all 256 bits, all checks, both sinks (rare: what the drain's filter lets through).
-__device__ __noinline__ void settle_pair(const HitCtx* __restrict__ ctx, uint32_t i, uint32_t j) {
-    const HitCtx c = load_ctx(ctx);
+// Row of accumulator register r of a lane whose rows start at ib (C/D layout of the 32x32 MFMA).
+__device__ __forceinline__ uint32_t qrow_of(uint32_t ib, uint32_t r) { return ib + (r & 3u) + 8u * (r >> 2); }
+
+// One candidate pair, all 256 bits, all checks, both sinks (rare: what the filter lets through).
+__device__ __forceinline__ void settle_pair(const HitCtx& c, uint32_t i, uint32_t j) {
     const bool rect = c.rect != 0u;
     if (!(j < c.n && (rect ? i < c.nq : i < j))) return;
     uint32_t d = 0;
@@ -414,62 +433,153 @@ __device__ __noinline__ void settle_pair(const HitCtx* __restrict__ ctx, uint32_
     }
 }
 
-// Settle all four queues (n0..n3 entries). Called by all 256 threads behind a barrier; the caller puts another barrier
-// behind it before anybody pushes again. Two entries per thread and round, their loads issued together: the cost of a
-// settlement is its memory round trips (the packed hashes are touched by nobody else: the loads miss L2), not its work.
-// With packed hashes the first look is at the 128 bits the first stage did NOT see (other_half: 0 = bits 0..127): 16 B per
-// hash, and of unrelated pairs that agreed in one half, 2e-4 agree in the other; those go on to settle_pair.
-__device__ __noinline__ void drain_queues_wg(const HitCtx* __restrict__ ctx, uint32_t n0_v, uint32_t n1_v, uint32_t n2_v,
-                                             uint32_t n3_v, uint32_t row0_v, uint32_t other_half_v, uint32_t tid) {
+// thread tid's share of the queues: entry number k of the concatenation (wave 0's entries, wave 1's, ...); *w = the wave
+__device__ __forceinline__ uint2* queue_entry(uint32_t k, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t* w_out) {
+    const uint32_t w = k < n0 ? 0u : k < n0 + n1 ? 1u : k < n0 + n1 + n2 ? 2u : 3u;
+    const uint32_t idx = k - (w == 0u ? 0u : w == 1u ? n0 : w == 2u ? n0 + n1 : n0 + n1 + n2);
+    *w_out = w;
+    return &g_wave_queue[w][idx];
+}
+
+// Settling the four queues (n0..n3 entries) takes two LEAF functions, both called by all 256 threads behind a barrier (the
+// caller puts another barrier behind them before anybody pushes again). Leaf, because a function that calls another keeps
+// its own values in the high callee-saved registers, and every register a callee touches is one the kernel cannot hold a
+// live value in across the call (a first version with nested calls: 167 VGPRs, 39 spills in the kernel's panel loop).
+//
+// 1. drain_filter_wg looks at the 128 bits the first stage did NOT see (other_half: 0 = bits 0..127) of the rows of each
+//    entry's first group, in the packed hashes: 16 B per hash; of unrelated pairs that agreed in one half, 2e-4 agree in the
+//    other. What this costs is line REQUESTS and rounds, not bytes (profiles/r04_k2_queue_ablation.txt): a lane's 16 bytes
+//    from a line of its own take the texture path a cycle each, and the other workgroups' panel prefetch queues behind
+//    them. So (a) the workgroup's own rows -- 1024 x 16 B -- are first copied, coalesced, into the panel buffer that is
+//    free at this point (rows_lds: 16 KB), and only an entry's COLUMN is a gather: one request per entry instead of four;
+//    (b) a thread takes three entries per round with their loads in flight together, and the queues are settled when they
+//    hold about one round's worth (kQDrainAt). The verdict goes back into the entry: x = groups still to do (bits 0..5) |
+//    rows of the first group that passed (bits 6..8) | the first group's number (bits 9..11) | row offset << 16.
+//    Returns non-zero if this thread left work for
+// 2. settle_marked_wg, which walks the same entries again: the rows that passed in full (settle_pair), an entry's further
+//    groups through the same filter first (rows_lds is still valid). Without packed hashes (image-only callers) every row
+//    of every group is its work.
+__device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx, uint32_t n0_v, uint32_t n1_v, uint32_t n2_v,
+                                                 uint32_t n3_v, uint32_t row0_v, uint32_t other_half_v, uint32_t tid,
+                                                 uint4* rows_generic) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    auto* rows_lds = (__attribute__((address_space(3))) uint4*)rows_generic;  // (ds_* instead of flat_* accesses)
     const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0_v), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1_v);
     const uint32_t n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n2_v), n3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n3_v);
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
-    const uint32_t oh = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
-#else
-    const uint32_t n0 = n0_v, n1 = n1_v, n2 = n2_v, n3 = n3_v, row0 = row0_v, oh = other_half_v;
-#endif
-    // (only what the filter needs is fetched here -- the full context is settle_pair's business: this function's register
-    // footprint is what the kernel has to keep clear of across the call)
-    const uint32_t total = n0 + n1 + n2 + n3;
-#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
     const auto* cc = (const __attribute__((address_space(4))) HitCtx*)uniform_u64((unsigned long long)ctx);
 #else
+    uint4* rows_lds = rows_generic;
+    const uint32_t n0 = n0_v, n1 = n1_v, n2 = n2_v, n3 = n3_v, row0 = row0_v, ohw = other_half_v;
     const HitCtx* cc = ctx;
 #endif
+    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
+    const uint32_t total = n0 + n1 + n2 + n3;
     const uint4* __restrict__ db_q = cc->db_q;
     const uint4* __restrict__ db_t = cc->db_t;
     const uint32_t max_dist = cc->max_dist;
-    const bool packed = db_t != nullptr;
+    if (db_t == nullptr) return 1u;  // launch-uniform: no packed hashes, the entries stay as they are (every group to do)
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 6  // timing-only ablation: the call and nothing else
+    return 0u;
+#endif
+    {
+        const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;  // rows beyond it are padding: never queued, never read
+#pragma unroll
+        for (uint32_t q = 0; q < kSuper * 8u / 256u; ++q) {
+            const uint32_t r = tid + 256u * q;
+            rows_lds[r] = db_q[(size_t)min(row0 + r, last) * 2u + oh];
+        }
+        __syncthreads();
+    }
+    constexpr int E = 3;
+    uint32_t left = 0;
 #pragma unroll 1
-    for (uint32_t k0 = 0; k0 < total; k0 += 256u) {
-        const uint32_t k = k0 + tid;
-        if (k >= total) continue;
-        const uint32_t w = k < n0 ? 0u : k < n0 + n1 ? 1u : k < n0 + n1 + n2 ? 2u : 3u;
-        const uint32_t idx = k - (w == 0u ? 0u : w == 1u ? n0 : w == 2u ? n0 + n1 : n0 + n1 + n2);
-        const uint2 e = g_wave_queue[w][idx];
-        uint32_t gm = e.x & 63u;
-        const uint32_t ib = row0 + (e.x >> 16) + 4u * (e.y & 1u), j = e.y >> 1;
+    for (uint32_t k0 = 0; k0 < total; k0 += 256u * E) {
+        uint32_t ex[E];
+        uint4 col[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const uint32_t k = k0 + tid + 256u * (uint32_t)u;
+            ex[u] = 0u;
+            col[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (k < total) {
+                uint32_t w;
+                const uint2 e = *queue_entry(k, n0, n1, n2, &w);
+                // (bits 15, 12..14 are free: h and the wave ride along so that y and w need not be held)
+                ex[u] = e.x | ((e.y & 1u) << 15) | (w << 12);
+                col[u] = db_t[(size_t)(e.y >> 1) * 2u + oh];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const uint32_t k = k0 + tid + 256u * (uint32_t)u;
+            if (k >= total) continue;
+            const uint32_t gm = ex[u] & 63u;
+            const uint32_t first = 31u - (uint32_t)__clz((int)gm);
+            const uint32_t rest = gm & ~(1u << first);
+            const uint32_t g = 5u - first, r0 = 3u * g;
+            const uint32_t ibrel = (ex[u] >> 16) + 4u * ((ex[u] >> 15) & 1u) + wrows * ((ex[u] >> 12) & 3u);  // relative to row0
+            // (group 5 = register 15 alone: its row three times)
+            const uint4 x0 = rows_lds[qrow_of(ibrel, r0)], x1 = rows_lds[qrow_of(ibrel, g == 5u ? r0 : r0 + 1u)],
+                        x2 = rows_lds[qrow_of(ibrel, g == 5u ? r0 : r0 + 2u)];
+            uint32_t pass = (sign_popc(x0, col[u], 0u) <= max_dist ? 1u : 0u) | (sign_popc(x1, col[u], 0u) <= max_dist ? 2u : 0u) |
+                            (sign_popc(x2, col[u], 0u) <= max_dist ? 4u : 0u);
+            if (g == 5u) pass &= 1u;
+            left |= pass | rest;
+            uint32_t w_;
+            queue_entry(k, n0, n1, n2, &w_)->x = (ex[u] & 0xFFFF0000u) | rest | (pass << 6) | (g << 9);
+        }
+    }
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 7  // timing-only ablation: the filter runs, nothing is settled
+    return 0u;
+#endif
+    return left;
+}
+
+__device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, uint32_t n0_v, uint32_t n1_v, uint32_t n2_v,
+                                              uint32_t n3_v, uint32_t row0_v, uint32_t other_half_v, uint32_t tid,
+                                              const uint4* rows_generic) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto* rows_lds = (const __attribute__((address_space(3))) uint4*)rows_generic;
+    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0_v), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1_v);
+    const uint32_t n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n2_v), n3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n3_v);
+    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
+    const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
+#else
+    const uint4* rows_lds = rows_generic;
+    const uint32_t n0 = n0_v, n1 = n1_v, n2 = n2_v, n3 = n3_v, row0 = row0_v, ohw = other_half_v;
+#endif
+    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
+    const HitCtx c = load_ctx(ctx);
+    const uint32_t total = n0 + n1 + n2 + n3;
+    const bool packed = c.db_t != nullptr;
 #pragma unroll 1
-        while (gm != 0u) {  // one round per set group bit: almost always one
+    for (uint32_t k = tid; k < total; k += 256u) {
+        uint32_t w;
+        const uint2 e = *queue_entry(k, n0, n1, n2, &w);
+        const uint32_t ibrel = (e.x >> 16) + 4u * (e.y & 1u) + wrows * w, j = e.y >> 1;
+        uint32_t gm = e.x & 63u, pass = (e.x >> 6) & 7u;
+        if ((gm | pass) == 0u) continue;
+        const uint32_t r0 = 3u * ((e.x >> 9) & 7u);
+#pragma unroll 1
+        while (pass != 0u) {  // rows of the first group that passed the filter
+            const uint32_t q = (uint32_t)__ffs((int)pass) - 1u;
+            pass &= pass - 1u;
+            settle_pair(c, row0 + qrow_of(ibrel, r0 + q), j);
+        }
+        if (gm == 0u) continue;
+        const uint4 col = packed ? c.db_t[(size_t)j * 2u + oh] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+        while (gm != 0u) {  // the groups nobody has looked at yet
             const uint32_t bit = 31u - (uint32_t)__clz((int)gm);
             gm &= ~(1u << bit);
-            const uint32_t g = 5u - bit, r0 = 3u * g, nr = g == 5u ? 1u : 3u;  // registers r0 .. r0 + nr - 1
-            const uint32_t i0 = ib + (r0 & 3u) + 8u * (r0 >> 2);
-            const uint32_t r1 = r0 + (nr > 1u ? 1u : 0u), r2 = r0 + (nr > 1u ? 2u : 0u);
-            const uint32_t i1 = ib + (r1 & 3u) + 8u * (r1 >> 2), i2 = ib + (r2 & 3u) + 8u * (r2 >> 2);
-            uint32_t pass = nr == 1u ? 1u : 7u;
-            if (packed) {
-                const uint4 col = db_t[(size_t)j * 2u + oh];
-                const uint4 x0 = db_q[(size_t)i0 * 2u + oh], x1 = db_q[(size_t)i1 * 2u + oh], x2 = db_q[(size_t)i2 * 2u + oh];
-                pass &= (sign_popc(x0, col, 0u) <= max_dist ? 1u : 0u) | (sign_popc(x1, col, 0u) <= max_dist ? 2u : 0u) |
-                        (sign_popc(x2, col, 0u) <= max_dist ? 4u : 0u);
-            }
+            const uint32_t g = 5u - bit, nr = g == 5u ? 1u : 3u;
 #pragma unroll 1
-            while (pass != 0u) {  // rare with packed hashes (2e-4 of the candidates)
-                const uint32_t q = (uint32_t)__ffs((int)pass) - 1u;
-                pass &= pass - 1u;
-                settle_pair(ctx, q == 0u ? i0 : q == 1u ? i1 : i2, j);
+            for (uint32_t q = 0; q < nr; ++q) {
+                const uint32_t rr = qrow_of(ibrel, 3u * g + q);
+                if (packed && sign_popc(rows_lds[rr], col, 0u) > c.max_dist) continue;
+                settle_pair(c, row0 + rr, j);
             }
         }
     }
@@ -578,8 +688,10 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
     const uint32_t nsp = (col1 - j0) / kSuper;  // col0, col1, j0 are multiples of kSuper
 
     const v16f zero = {c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1};  // the accumulators' start value
-    uint32_t qn = 0;  // QUEUE: entries waiting in this wave's pair queue (wave-uniform)
-    const uint32_t qcol = (li << 1) | h;  // QUEUE: this lane's share of an entry's y word: (column << 1) | h
+    // QUEUE: index of this wave's next free slot in the (flattened) queue array (wave-uniform) -- the fill level and the
+    // wave's base in one scalar -- and this lane's share of an entry's y word: (column << 1) | h
+    uint32_t qidx = wave * kQWaveCap;
+    const uint32_t qcol = (li << 1) | h;
 
     // The two LDS buffers are separate objects and the super-panel loop is unrolled by two, so that every
     // ds_read names one array and every in-flight global->LDS load the other: with one two-dimensional array
@@ -636,14 +748,17 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
                         return;
                     }
                     if (gm != 0u) {
-                        const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-                        // x: wave-uniform but for the mask (one v_or with an SGPR); the lane's half h rides in bit 0 of y, next to
-                        // the column, whose lane-constant part is a register the loop holds anyway (a per-lane row offset here
-                        // cost a register that the allocator spilled: a scratch reload -- and its vmcnt(0), which also waits
-                        // for the panel prefetch -- in every note)
-                        g_wave_queue[wave][slot] = make_uint2(gm | ((wave * WROWS + 32u * (uint32_t)t) << 16), ((jsp + 32u * p) << 1) + qcol);
+                        // Nothing in an entry but the mask is the lane's own business or the wave's: the tile is a literal, the
+                        // wave follows from the queue the entry sits in, the lane's half h rides in bit 0 of y next to the
+                        // column, whose lane-constant part is a register the loop holds anyway -- and the queue's index is the
+                        // fill level itself (qidx; the array stays NAMED in the store: through a bare LDS address the compiler
+                        // cannot tell it from the panel buffers and waits for the prefetch in flight, vmcnt(0), first). Every per-lane or per-wave constant tried here ended up spilled (a scratch
+                        // reload whose vmcnt(0) also waits for the panel prefetch; v_readlane of spilled SGPRs), in a path that
+                        // a fifth of all tiles take.
+                        const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                        (&g_wave_queue[0][0])[qidx + mb] = make_uint2(gm | ((32u * (uint32_t)t) << 16), ((jsp + 32u * p) << 1) + qcol);
                     }
-                    qn += nl;
+                    qidx += nl;
                 };
                 static_assert(kSign, "the pair-queue form reads sign bits (HVD_K2_SIGN=1)");
                 auto hit = [&](const Or16Groups& o) { return __any(o.all < 0); };
@@ -726,10 +841,10 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
     // the same four numbers -- whether to settle the queues now (drain_queues_wg).
     auto publish = [&]() {
         if constexpr (QUEUE) {
-            if (lane == 0u) g_wave_qn[wave] = qn;
+            if (lane == 0u) g_wave_qn[wave] = qidx - wave * kQWaveCap;
         }
     };
-    auto settle = [&](const bool final) {
+    auto settle = [&](const bool final, uint4* free_panel) {
         if constexpr (QUEUE) {
             const uint4 q4 = *reinterpret_cast<const uint4*>(g_wave_qn);
             const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.x), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.y);
@@ -737,9 +852,10 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
             const uint32_t sum = n0 + n1 + n2 + n3, mx = max(max(n0, n1), max(n2, n3));
             if (final ? sum != 0u : (sum >= kQDrainAt || mx > kQWaveCap - kQSuperMax)) {
 #if !(defined(HVD_K2_QABL) && HVD_K2_QABL == 3)  // 3 = pushed entries are dropped instead of settled
-                drain_queues_wg(ctx, n0, n1, n2, n3, row0, selx ? 0u : 1u, wave * 64u + lane);
+                const uint32_t left = drain_filter_wg(ctx, n0, n1, n2, n3, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                if (__builtin_expect(__any(left != 0u), 0)) settle_marked_wg(ctx, n0, n1, n2, n3, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
 #endif
-                qn = 0;
+                qidx = wave * kQWaveCap;
                 __syncthreads();  // nobody pushes (or publishes) again before everybody has read the queues
             }
         }
@@ -756,14 +872,14 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
         publish();
         __syncthreads();  // (drains the in-flight global->LDS loads with vmcnt(0) first)
         if (sp + 1u >= nsp) break;
-        settle(false);
+        settle(false, lds0);  // (lds0 has just been used up and is not refilled before the settlement is over)
         if (sp + 2u < nsp) stage_super_panel(img + (size_t)(jsp + 2u * kSuper) * 8u, lds0, wave, lane);
         process(lds1, jsp + kSuper);
         publish();
         __syncthreads();
-        if (sp + 2u < nsp) settle(false);
+        if (sp + 2u < nsp) settle(false, lds1);
     }
-    settle(true);
+    settle(true, lds0);  // (nothing is in flight any more: both buffers are free)
     // every path leaves the loop through a barrier: all hits of this workgroup are in LDS now
     flush_pairs_wg(ctx, wave * 64u + lane);
 }
@@ -866,8 +982,16 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
 
 // auto variant (13): the form for data with common false survivors (15 = pair queue; 0 = none, i.e. round 3's two-way choice)
 // and the survivor density (per 1024-pair tile, as the probe estimates it) up to which it is preferred over the register form
+uint32_t g_mfma_queue_packed = 1;  // 0: the pair queue settles from the FP4 images even when packed hashes are at hand (tests)
 uint32_t g_mfma_auto_mid = 15;
 uint32_t g_mfma_auto_mid_max_x100 = 200;
+hipError_t launch_pack_fp4(const void* d_img, uint32_t n, void* d_db, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)n * 8u;
+    hipLaunchKernelGGL(k_pack_fp4, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const uint4*)d_img, n, (uint32_t*)d_db);
+    return hipGetLastError();
+}
+
 uint32_t g_mfma_col_chunk_max = 8192;  // tuning knob (hvd_debug_set "mfma_col_chunk_max"); 2048..32768 within 3 %
 
 static uint32_t pick_col_chunk_m(uint32_t n_pad, uint32_t rows_per_wg) {
@@ -928,7 +1052,7 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
     c.img_t = (const uint4*)d_img_t;
     c.db_t = (const uint4*)a.d_db;
     c.db_q = (const uint4*)(rect ? a.d_db_q : a.d_db);
-    if (c.db_q == nullptr || c.db_t == nullptr) c.db_q = c.db_t = nullptr;
+    if (c.db_q == nullptr || c.db_t == nullptr || !g_mfma_queue_packed) c.db_q = c.db_t = nullptr;
     c.max_dist = a.max_dist;
     uint32_t* sel = nullptr;
     c.qstats = mfma_select_buffer(&sel) == hipSuccess ? reinterpret_cast<unsigned long long*>(sel + 128) : nullptr;

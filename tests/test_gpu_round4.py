@@ -1,0 +1,155 @@
+"""Round-4 GPU parity tests: the pair-queue form of the FP4-MFMA all-pairs kernel (variant 15: first-stage survivors
+settled pair by pair on the VALU instead of tile by tile on the matrix pipe) -- chosen by the probe on real frame hashes,
+in frame-pair, video and cross mode, with and without packed hashes, and on the data that overflows its queues -- all
+through the C-ABI, against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sorted_pairs(p):
+    return p[np.lexsort((p["j"], p["i"]))]
+
+
+def _auto(gpu, key):
+    v = C.c_int(0)
+    gpu.check(gpu.load().hvd_debug_get(key, C.byref(v)))
+    return v.value
+
+
+def _run(gpu, hvd, db, variant, group=None, max_dist=31, cap=1 << 16):
+    n = len(db)
+    d_db = gpu.DeviceBuffer.from_array(db)
+    d_img = hvd.multigpu.expand_fp4(d_db.ptr, n)
+    d_grp = gpu.DeviceBuffer.from_array(group) if group is not None else None
+    d_pairs, d_cnt = gpu.DeviceBuffer(16 * cap), gpu.DeviceBuffer(8)
+    d_cnt.zero()
+    hvd.multigpu.launch_allpairs(gpu.load(), d_db.ptr, d_img.ptr, n, d_grp.ptr if d_grp else None, max_dist, 0, 1,
+                                 d_pairs.ptr, cap, d_cnt.ptr, variant)
+    cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+    assert cnt <= cap
+    got = _sorted_pairs(d_pairs.to_array(gpu.PAIR_DTYPE, cnt))
+    for b in (d_db, d_img, d_pairs, d_cnt, d_grp):
+        if b is not None:
+            b.free()
+    return got
+
+
+@pytest.fixture(scope="module")
+def frame_library(gpu, hvd):
+    """Hashes of synthetic VIDEO FRAMES (the config-5 generator): the data on which the first 128 bits of unrelated hashes
+    agree within the tolerance for ~2e-4 of all pairs. 1 500 videos x 64 frames, 2 % planted copies."""
+    from hvd_amd import pipeline
+    lib = gpu.load()
+    V, F = 1500, 64
+    rng = np.random.default_rng(41)
+    copy_of = np.full(V, -1, dtype=np.int32)
+    dst = rng.choice(np.arange(V // 2, V), V // 50, replace=False)
+    copy_of[dst] = rng.integers(0, V // 2, dst.size)
+    d_copy = gpu.DeviceBuffer.from_array(copy_of)
+    d_frames = gpu.DeviceBuffer(V * F * 4096)
+    gpu.check(lib.hvd_dev_synth_video_frames(d_frames.ptr, 0, V, F, 5, d_copy.ptr))
+    d_h, d_q = pipeline.hash_frames_on_device(d_frames.ptr, V * F, 64, 64, 1)
+    libr = pipeline.DeviceLibrary.from_raw_hashes(d_h.ptr, d_q.ptr, V * F, np.arange(V + 1, dtype=np.int64) * F)
+    for b in (d_frames, d_copy, d_h, d_q):
+        b.free()
+    frames, offsets = libr.hashes(), libr.offsets()
+    video = np.repeat(np.arange(V, dtype=np.int32), np.diff(offsets))
+    yield frames, offsets, video, libr
+    libr.free()
+
+
+def test_k2_probe_picks_the_pair_queue_on_frame_hashes(gpu, hvd, oracle, frame_library):
+    frames, offsets, video, _ = frame_library
+    want = oracle.allpairs(frames, 31, group=video, num_threads=8, cap=1 << 22)
+    assert len(want) > 1000  # the planted copies
+    got = _run(gpu, hvd, frames, 13, group=video, cap=len(want) + 16)
+    assert _auto(gpu, b"mfma_auto_form") == 15 and _auto(gpu, b"mfma_probe_survivors") > 100
+    assert np.array_equal(got, want)
+    for v in (15, 12, 9):
+        assert np.array_equal(_run(gpu, hvd, frames, v, group=video, cap=len(want) + 16), want), v
+    assert np.array_equal(_run(gpu, hvd, frames, 15, cap=1 << 20), oracle.allpairs(frames, 31, num_threads=8, cap=1 << 22))
+
+
+def test_k2_pair_queue_settles_from_the_images_when_there_are_no_packed_hashes(gpu, hvd, oracle, frame_library):
+    frames, offsets, video, _ = frame_library
+    sub = frames[:30000]
+    want = oracle.allpairs(sub, 31, group=video[:30000], num_threads=8, cap=1 << 22)
+    lib = gpu.load()
+    gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 0))
+    try:
+        assert np.array_equal(_run(gpu, hvd, sub, 15, group=video[:30000], cap=len(want) + 16), want)
+    finally:
+        gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 1))
+
+
+def test_k3_video_search_runs_through_the_pair_queue(gpu, hvd, oracle, frame_library):
+    frames, offsets, video, libr = frame_library
+    got = libr.match_videos(31)
+    assert _auto(gpu, b"mfma_auto_form") == 15
+    # oracle on a sub-library (every video pair of the first 400 videos + all planted copies are checked by recall below)
+    sub_v = 400
+    sub = oracle.match_videos(frames[: offsets[sub_v]], offsets[: sub_v + 1], 31)
+    mine = got[(got["a"] < sub_v) & (got["b"] < sub_v)]
+    assert np.array_equal(mine, sub)
+    # the forms agree on the whole library
+    lib = gpu.load()
+    gpu.check(lib.hvd_debug_set(b"mfma_auto_mid", 0))
+    try:
+        ref = libr.match_videos(31)
+        assert _auto(gpu, b"mfma_auto_form") == 12
+    finally:
+        gpu.check(lib.hvd_debug_set(b"mfma_auto_mid", 15))
+    assert np.array_equal(got, ref) and len(got) > 20
+    gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 0))
+    try:
+        assert np.array_equal(libr.match_videos(31), ref)
+    finally:
+        gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 1))
+
+
+def test_k3_cross_search_runs_through_the_pair_queue(gpu, hvd, oracle, frame_library):
+    frames, offsets, video, _ = frame_library
+    V = len(offsets) - 1
+    q_sel = np.arange(0, 300, 2)
+    lengths = np.diff(offsets)
+    q_off = np.zeros(q_sel.size + 1, dtype=np.int64)
+    np.cumsum(lengths[q_sel], out=q_off[1:])
+    q_frames = np.concatenate([frames[offsets[v]:offsets[v + 1]] for v in q_sel])
+    t_v = 600
+    got = hvd.search.match_videos_cross(q_frames, q_off, frames[: offsets[t_v]], offsets[: t_v + 1],
+                                        ids_q=q_sel.astype(np.int32), ids_t=np.arange(t_v, dtype=np.int32))
+    assert _auto(gpu, b"mfma_auto_form") == 15
+    want = []
+    for qi, v in enumerate(q_sel):
+        a = frames[offsets[v]:offsets[v + 1]].tobytes()
+        for t in range(t_v):
+            if t == v:
+                continue
+            q, th = oracle.match_two(a, frames[offsets[t]:offsets[t + 1]].tobytes(), 31)
+            if q or th:
+                want.append((qi, t, q, th))
+    assert got.tolist() == want
+
+
+def test_k2_pair_queue_overflowing_tiles_take_the_tile_route(gpu, hvd, oracle):
+    """Tiles in which many lanes hold a survivor (a cluster of near-identical hashes, the diagonal) leave the queue alone;
+    queues that fill up inside one super-panel are settled before they overflow: half the DB agrees in its first 128 bits
+    (every tile of that half survives the first stage in every lane), the other half is uniform."""
+    rng = np.random.default_rng(77)
+    n = 6000
+    db = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    db[: n // 2, :16] = rng.integers(0, 256, 16, dtype=np.uint8)  # one common lower half
+    # sparse survivors as well: 3 survivors per 32x32 tile on average in the uniform half (prototypes in the lower half)
+    proto = rng.integers(0, 256, (340, 16), dtype=np.uint8)
+    db[n // 2:, :16] = proto[rng.integers(0, 340, n - n // 2)]
+    db[100] = db[5000]
+    db[4000, :] = db[3500, :]
+    db[4000, 20] ^= 0x3
+    want = oracle.allpairs(db, 31, num_threads=8, cap=1 << 22)
+    assert len(want) >= 2
+    for v in (15, 12):
+        assert np.array_equal(_run(gpu, hvd, db, v, cap=len(want) + 16), want), v
