@@ -489,16 +489,20 @@ def main():
             L.check(lib.hvd_dev_synth_video_frames(d_frames.ptr, v_lo, v_hi - v_lo, F, 5, d_copy.ptr))
             raw_off = np.arange(V + 1, dtype=np.int64) * F
             pipeline.dedupe_frames_on_device(d_frames.ptr, raw_off, 64, 64, 1, 50.0, None, rank, world, exchange)  # warm-up
-            times = []
+            times, stage5 = [], []
             for _ in range(3):
                 barrier()
                 t0 = time.perf_counter()
+                tm5 = {}
                 pairs5, recs5, lib5 = pipeline.dedupe_frames_on_device(d_frames.ptr, raw_off, 64, 64, 1, 50.0, None, rank,
-                                                                       world, exchange, keep_library=True)
+                                                                       world, exchange, keep_library=True, timings=tm5)
                 barrier()
                 times.append(rdzv.allreduce_max([time.perf_counter() - t0])[0])
+                stage5.append(rdzv.allreduce_max([tm5["hash_ms"], tm5["search_ms"]]))
                 kept5, lens5 = lib5.n_frames, lib5.lengths()
                 lib5.free()
+            fv5 = C.c_int(0)
+            L.check(lib.hvd_debug_get(b"mfma_auto_form", C.byref(fv5)))
             d_frames.free()
             d_copy.free()
             planted5 = {(int(min(s, d)), int(max(s, d))) for d, s in enumerate(copy_of) if s >= 0}
@@ -509,6 +513,25 @@ def main():
             assert len(set(chk)) == 1, "ranks disagree on the config-5 records"
             t5, t5_sd = mean_sd(times)
             fcmp5 = float((lens5.sum() ** 2 - (lens5 ** 2).sum()) / 2)  # frame comparisons between different videos
+            hash5_ms, _ = mean_sd([x[0] for x in stage5])
+            search5_ms, search5_sd = mean_sd([x[1] for x in stage5])
+            # the search's kernel walks every tile of the upper triangle of kept x kept frames (pairs inside one video are
+            # computed and then dropped): 2 MFMAs of 2*32*32*64 flop per 1024 comparisons in the first stage; the forms that
+            # settle survivors on the matrix pipe execute more (PMC: profiles/r04_pmc_k2_*), the pair-queue form does not
+            exec_cmp5 = float(kept5) * (float(kept5) - 1.0) / 2.0 / world
+            flop5 = exec_cmp5 / 1024.0 * 2.0 * 131072.0
+            search5 = {"ms": round(search5_ms, 3), "ms_sd": round(search5_sd, 3), "form": int(fv5.value),
+                       "form_name": {9: "fetch", 12: "register cascade", 15: "pair queue"}.get(int(fv5.value), "?"),
+                       "frame_comparisons_per_s": sig(fcmp5 / (search5_ms * 1e-3)),
+                       "executed_comparisons_per_s": sig(exec_cmp5 * world / (search5_ms * 1e-3)),
+                       "note": "HIP-event time of the whole hvd_dev_vpdq_match_videos call on the library stream (packed hashes, "
+                               "probe, all-pairs pass in video mode, key reduction, record emit; max over ranks)",
+                       "roofline": {"bound": "mfma", "kernel": f"k_allpairs_mfma (video mode, form {int(fv5.value)} chosen by the probe)",
+                                    "achieved": sig(flop5 / (search5_ms * 1e-3) / 1e12), "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(flop5 / (search5_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS, 4),
+                                    "flop_per_launch": flop5,
+                                    "basis": "first-stage MFMAs only (2 per 1024 executed comparisons, per rank) over the time of the "
+                                             "whole call; counters: profiles/r04_pmc_k2_structured15.txt", "traffic": None}}
             extras["cfg5"] = {"workload": f"BASELINE configs[4]: {V} synthetic videos x {F} distinct 64x64 frames generated in HBM -> PDQ hash -> "
                                 "quality filter + CSR on the GPU -> FP4 image -> all video pairs with the vPDQ counters reduced on "
                                 f"the GPU -> pair predicate (threshold 50); {world} GPU(s): frames hashed in disjoint video ranges, "
@@ -516,6 +539,7 @@ def main():
                     "seconds": round(t5, 4), "seconds_sd": round(t5_sd, 4), "n_gpus": world,
                     "frames": V * F, "frames_kept": int(kept5), "videos_per_s": sig(V / t5), "frames_per_s_end_to_end": sig(V * F / t5),
                     "frame_comparisons": fcmp5, "frame_comparisons_per_s_end_to_end": sig(fcmp5 / t5),
+                    "hash_ms": round(hash5_ms, 3), "search": search5,
                     "video_records": int(len(recs5)), "duplicate_pairs": int(len(pairs5)),
                     "planted_copies": len(planted5), "planted_recall": round(len(planted5 & found5) / max(1, len(planted5)), 4),
                     "gate": "identical record checksum on every rank; tests/test_gpu_round2.py checks the same pipeline against "
@@ -570,7 +594,7 @@ def main():
                          "because tiles re-use operands from registers/LDS"}
     if variant >= 8:
         # executed matrix work: 2 (128-bit first stage) or 4 MFMAs of 2*32*32*64 flop per 1024 comparisons
-        flop_per_cmp = 256.0 if form in (9, 11, 12) else 512.0
+        flop_per_cmp = 256.0 if form in (9, 11, 12, 15) else 512.0
         tfl = cmp_per_launch * flop_per_cmp / (kernel_avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": f"k_allpairs_mfma(variant={variant}" + (f" -> form {form} chosen by the probe)" if variant == 13 else ")"),
                     "achieved": round(tfl, 1),
@@ -668,7 +692,8 @@ def main():
 
         # every exact form next to the default, for transparency (same DB, same launch shape)
         for v, name in ((0, "popcount_full_16op"), (1, "popcount_prefilter128"), (8, "mfma_fp4_full_256"),
-                        (9, "mfma_fp4_stage128_fetch"), (12, "mfma_fp4_stage128_registers")):
+                        (9, "mfma_fp4_stage128_fetch"), (12, "mfma_fp4_stage128_registers"),
+                        (15, "mfma_fp4_stage128_pair_queue")):
             mu, sd, _ = time_variant(v, reps=3)
             extra[name] = {"kernel_ms": round(mu, 3), "kernel_ms_sd": round(sd, 3), "comparisons_per_s": sig(total_cmp / (mu * 1e-3))}
         out["kernel_variants"] = extra

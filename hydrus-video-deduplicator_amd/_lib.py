@@ -78,7 +78,9 @@ SIGNATURES = {
     "hvd_dev_vpdq_emit_again": (_int, [_vp, _i64, _vp]),
     "hvd_dev_vpdq_match_videos_cross": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _int, _int, _int, _vp, _i64,
                                                _vp]),
+    # include/hvd_mi355x_bench.h (tests / bench only, not part of the drop-in boundary)
     "hvd_dev_synth_video_frames": (_int, [_vp, _i64, _i64, _int, C.c_uint64, _vp]),
+    "hvd_debug_parallel_copy": (_int, [_vp, _vp, C.c_size_t, _int]),
     "hvd_allpairs_tile_geometry": (_int, [_i64, _int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "hvd_timer_start": (_int, []),
     "hvd_timer_stop": (_int, [C.POINTER(C.c_float)]),

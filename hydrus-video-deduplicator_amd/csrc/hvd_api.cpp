@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "hvd_kernels.h"
+#include "../../include/hvd_mi355x_bench.h"
 
 namespace {
 
@@ -1215,6 +1216,7 @@ int hvd_dev_vpdq_match_videos_cross(const void* d_img_q, int64_t nq, const void*
     return HVD_OK;
 }
 
+#ifndef HVD_NO_BENCH_SYMBOLS
 int hvd_dev_synth_video_frames(void* d_frames, int64_t v0, int64_t n_videos, int frames_per_video, uint64_t seed,
                                const void* d_copy_of) {
     if (int rc = need_ready()) return rc;
@@ -1227,6 +1229,8 @@ int hvd_dev_synth_video_frames(void* d_frames, int64_t v0, int64_t n_videos, int
                                        (const int32_t*)d_copy_of, g.stream));
     return HVD_OK;
 }
+
+#endif  // HVD_NO_BENCH_SYMBOLS
 
 /* ------------------------------------------------------- RCCL exchange ---- */
 

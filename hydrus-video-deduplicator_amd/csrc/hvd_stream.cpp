@@ -53,6 +53,12 @@ struct Slot {
 // microseconds after a job (frames arrive back to back) and then sleep on a condition variable, so an idle hasher costs
 // nothing. Small frames (64x64) are copied by the caller alone.
 namespace {
+// Protocol (round 4; the first version published ONE shared job description behind a generation counter, and a helper that
+// took no part in job G could read job G+1's fields while still believing it was looking at G -- copy G+1's slice, count
+// itself done, then run G+1 again: the caller could return while a slice was still being written):
+// every helper has its OWN mailbox. The caller writes a participant's slice into its mailbox and then bumps that helper's
+// ticket; a helper reads nothing but its own mailbox, and only after its own ticket moved; the caller does not touch that
+// mailbox again before the helper has counted itself done. Helpers that take no part in a job are not involved in it at all.
 class CopyPool {
   public:
     static constexpr int kMaxHelpers = 7;
@@ -69,15 +75,25 @@ class CopyPool {
         }
         std::lock_guard<std::mutex> job_lk(job_mu_);  // one job at a time (two hashers on two threads take turns)
         ensure_helpers(parts - 1);
-        parts = std::min(parts, (int)th_.size() + 1);
-        const size_t slice = (n / (size_t)parts + 63) & ~(size_t)63;
-        src_ = src;
-        dst_ = dst;
-        n_ = n;
-        slice_ = slice;
-        parts_ = parts;
-        pending_.store(parts - 1, std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_release);
+        parts = std::min(parts, n_helpers_ + 1);
+        // (ceiling: with n / parts the last n % parts bytes belonged to nobody whenever n / parts was a multiple of 64 --
+        // found by tests/test_copy_pool.py; the reference's 786 432-byte frames divide evenly, other geometries need not)
+        const size_t slice = ((n + (size_t)parts - 1) / (size_t)parts + 63) & ~(size_t)63;
+        int given = 0;
+        for (int id = 1; id < parts; ++id) {
+            const size_t off = slice * (size_t)id;
+            if (off >= n) break;
+            ++given;
+        }
+        pending_.store(given, std::memory_order_relaxed);
+        for (int id = 1; id <= given; ++id) {
+            Box& b = box_[id - 1];
+            const size_t off = slice * (size_t)id;
+            b.src = src + off;
+            b.dst = dst + off;
+            b.len = std::min(slice, n - off);
+            b.ticket.fetch_add(1, std::memory_order_release);
+        }
         if (sleepers_.load(std::memory_order_acquire) > 0) {
             std::lock_guard<std::mutex> lk(mu_);
             cv_.notify_all();
@@ -87,19 +103,25 @@ class CopyPool {
     }
 
     void stop() {
+        std::lock_guard<std::mutex> job_lk(job_mu_);  // never under a running copy(): its helpers would vanish
         {
             std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
+            stop_.store(true, std::memory_order_release);
             cv_.notify_all();
         }
-        gen_.fetch_add(1, std::memory_order_release);
-        for (std::thread& t : th_)
-            if (t.joinable()) t.join();
-        th_.clear();
-        stop_ = false;
+        for (int i = 0; i < n_helpers_; ++i)
+            if (th_[i].joinable()) th_[i].join();
+        n_helpers_ = 0;
+        stop_.store(false, std::memory_order_release);
     }
 
   private:
+    struct alignas(64) Box {
+        std::atomic<uint64_t> ticket{0};
+        const uint8_t* src = nullptr;
+        uint8_t* dst = nullptr;
+        size_t len = 0;
+    };
     static void cpu_relax() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -107,49 +129,53 @@ class CopyPool {
     }
     void ensure_helpers(int want) {
         want = std::min(want, kMaxHelpers);
-        while ((int)th_.size() < want) {
-            const int id = (int)th_.size() + 1;  // slice index of this helper
-            const uint64_t start_gen = gen_.load(std::memory_order_acquire);
-            th_.emplace_back([this, id, start_gen] { run(id, start_gen); });
+        while (n_helpers_ < want) {
+            const int idx = n_helpers_;
+            const uint64_t seen = box_[idx].ticket.load(std::memory_order_acquire);
+            th_[idx] = std::thread([this, idx, seen] { run(idx, seen); });
+            ++n_helpers_;
         }
     }
-    void run(int id, uint64_t seen) {
+    void run(int idx, uint64_t seen) {
+        Box& b = box_[idx];
         for (;;) {
             int spins = 0;
-            while (gen_.load(std::memory_order_acquire) == seen) {
+            while (b.ticket.load(std::memory_order_acquire) == seen) {
+                if (stop_.load(std::memory_order_acquire)) return;
                 if (++spins < 20000) {
                     cpu_relax();
                     continue;
                 }
                 std::unique_lock<std::mutex> lk(mu_);
                 sleepers_.fetch_add(1, std::memory_order_release);
-                cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_acquire) != seen; });
+                cv_.wait(lk, [&] { return stop_.load(std::memory_order_acquire) || b.ticket.load(std::memory_order_acquire) != seen; });
                 sleepers_.fetch_sub(1, std::memory_order_release);
                 spins = 0;
             }
-            if (stop_) return;
-            seen = gen_.load(std::memory_order_acquire);
-            if (id < parts_) {
-                const size_t off = slice_ * (size_t)id;
-                if (off < n_) memcpy(dst_ + off, src_ + off, std::min(slice_, n_ - off));
-                pending_.fetch_sub(1, std::memory_order_release);
-            }
+            ++seen;  // tickets move by one per job and the caller waits for this helper before the next
+            memcpy(b.dst, b.src, b.len);
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
 
-    std::vector<std::thread> th_;
+    std::thread th_[kMaxHelpers];
+    Box box_[kMaxHelpers];
+    int n_helpers_ = 0;  // guarded by job_mu_
     std::mutex job_mu_, mu_;
     std::condition_variable cv_;
-    std::atomic<uint64_t> gen_{0};
     std::atomic<int> pending_{0}, sleepers_{0};
     std::atomic<bool> stop_{false};
-    const uint8_t* src_ = nullptr;
-    uint8_t* dst_ = nullptr;
-    size_t n_ = 0, slice_ = 0;
-    int parts_ = 0;
 };
 CopyPool g_copy_pool;
 }  // namespace
+
+#ifndef HVD_NO_BENCH_SYMBOLS
+extern "C" int hvd_debug_parallel_copy(void* dst, const void* src, size_t n, int threads) {
+    if ((!dst || !src) && n) return hvd::api_fail(HVD_ERR_ARG, "NULL buffer");
+    g_copy_pool.copy((uint8_t*)dst, (const uint8_t*)src, n, threads);
+    return HVD_OK;
+}
+#endif
 
 struct hvd_hasher {
     int copy_threads = 4;  // threads that share one frame's copy into the ring (hvd_hasher_set_threads)

@@ -216,18 +216,32 @@ def gather_hash_shards(d_h: DeviceBuffer, d_q: DeviceBuffer, raw_offsets: np.nda
 
 def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, w: int, channels: int,
                             threshold: float = 50.0, policy: str | None = None, rank: int = 0, world: int = 1,
-                            exchange=None, keep_library: bool = False):
+                            exchange=None, keep_library: bool = False, timings: dict | None = None):
     """BASELINE config 5 for one rank: the frames of videos [v_lo, v_hi) of this rank sit at d_frames_ptr
     (world == 1: all of them); raw_offsets is the CSR of the WHOLE library. Hash -> (all-gather of the hash
     shards) -> quality filter + CSR -> FP4 image -> sharded video search with the counters reduced on the GPU
     -> pair predicate of dedup.py:445-502 on the few video-level records.
-    -> (pairs int64[m,2], records, library or None). Every rank returns the same result."""
+    -> (pairs int64[m,2], records, library or None). Every rank returns the same result.
+    timings (optional dict): receives hash_ms and search_ms, HIP-event times on the library stream of the hash launch
+    and of the whole video search (image, probe, all-pairs pass, key reduction, record emit)."""
     raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.int64)
     V = raw_offsets.size - 1
     n_total = int(raw_offsets[-1])
     v_lo, v_hi = video_range_of_rank(V, rank, world)
     n_mine = int(raw_offsets[v_hi] - raw_offsets[v_lo])
-    d_h, d_q = hash_frames_on_device(d_frames_ptr, n_mine, h, w, channels)
+    lib = _lib.ensure()
+
+    def timed(key, fn):
+        if timings is None:
+            return fn()
+        _lib.check(lib.hvd_timer_start())
+        out = fn()
+        ms = C.c_float(0)
+        _lib.check(lib.hvd_timer_stop(C.byref(ms)))
+        timings[key] = float(ms.value)
+        return out
+
+    d_h, d_q = timed("hash_ms", lambda: hash_frames_on_device(d_frames_ptr, n_mine, h, w, channels))
     if world > 1:
         if exchange is None:
             raise ValueError("world > 1 needs the RCCL exchange")
@@ -238,7 +252,7 @@ def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, 
     library = DeviceLibrary.from_raw_hashes(d_h.ptr, d_q.ptr, n_total, raw_offsets)
     d_h.free()
     d_q.free()
-    recs = library.match_videos(rank=rank, world=world)
+    recs = timed("search_ms", lambda: library.match_videos(rank=rank, world=world))
     pairs = search.similar_video_pairs(recs, library.lengths(), threshold, policy)
     if keep_library:
         return pairs, recs, library

@@ -251,13 +251,6 @@ int hvd_dev_vpdq_match_videos_cross(const void* d_img_q, int64_t nq, const void*
                                     const void* d_img_t, int64_t nt, const void* d_video_t, const void* d_excl_t,
                                     int max_dist, int rank, int world, void* d_out, int64_t cap, void* d_count);
 
-/* Workload generator (tests / bench.py, BASELINE config 5): writes n_videos * frames_per_video synthetic 64x64 gray
- * frames for videos [v0, v0 + n_videos) to d_frames. Every frame is a pure function of (seed, video, frame index):
- * smooth random field + noise, ~5 % exact constants; d_copy_of (int32 per video of the WHOLE library, indexed by
- * absolute video number, or NULL): videos with copy_of[v] = s >= 0 are video s with +-2 noise per pixel. */
-int hvd_dev_synth_video_frames(void* d_frames, int64_t v0, int64_t n_videos, int frames_per_video, uint64_t seed,
-                               const void* d_copy_of);
-
 /* Host-only: the tile geometry hvd_dev_allpairs_hamming256 uses for (n, variant): a
  * tile is rows [rb*rows_per_block, +rows_per_block) x columns [cb*col_chunk, +col_chunk). */
 int hvd_allpairs_tile_geometry(int64_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);

@@ -10,9 +10,21 @@ import pytest
 from conftest import ROOT
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "hvd_mi355x.h")).read()
-    return sorted(set(re.findall(r"^\s*int\s+(hvd_\w+)\s*\(", text, flags=re.M)))
+def declared_symbols(headers=("hvd_mi355x.h", "hvd_mi355x_bench.h")):
+    """Every function include/*.h declares: the drop-in boundary (hvd_mi355x.h) and the tests' / bench's own entry points
+    (hvd_mi355x_bench.h: workload generator, test hook -- deliberately a separate header)."""
+    syms = []
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        syms += re.findall(r"^\s*int\s+(hvd_\w+)\s*\(", text, flags=re.M)
+    return sorted(set(syms))
+
+
+def test_bench_symbols_are_not_in_the_product_header():
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["hvd_mi355x.h", "hvd_mi355x_bench.h"]
+    product = declared_symbols(("hvd_mi355x.h",))
+    assert "hvd_dev_synth_video_frames" not in product and "hvd_debug_parallel_copy" not in product
+    assert declared_symbols(("hvd_mi355x_bench.h",)) == ["hvd_debug_parallel_copy", "hvd_dev_synth_video_frames"]
 
 
 def test_header_symbols_all_exported_and_bound(hvd):
@@ -22,7 +34,7 @@ def test_header_symbols_all_exported_and_bound(hvd):
     syms = declared_symbols()
     assert len(syms) >= 25
     for s in syms:
-        assert hasattr(lib, s), f"{s} declared in include/hvd_mi355x.h but not exported"
+        assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
     assert lib.hvd_abi_version() == 3
 

@@ -153,3 +153,54 @@ def test_k2_pair_queue_overflowing_tiles_take_the_tile_route(gpu, hvd, oracle):
     assert len(want) >= 2
     for v in (15, 12):
         assert np.array_equal(_run(gpu, hvd, db, v, cap=len(want) + 16), want), v
+
+
+# ---------------------------------------------------------------- streaming hasher ----
+
+def test_videohasher_two_threads_with_different_copy_thread_counts(gpu, hvd, oracle):
+    """Two threads push 512x512 RGB24 frames through hashers with num_threads 2 and 8 (the copy pool is one per process:
+    the pushers alternate job by job with different numbers of participants -- the setting of round 3's generation race),
+    one of them through the reference's geometry in gray as well; every hash of every video is compared."""
+    import threading
+
+    rgb = hvd.synth.frames_rgb(8, seed=52)
+    want_h, want_q = oracle.hash_frames(rgb)
+    assert (want_q >= 31).all()
+    errors = []
+
+    def pusher(num_threads, videos, frames_per_video, phase):
+        try:
+            blobs = [f.tobytes() for f in rgb]
+            for v in range(videos):
+                h = hvd.VideoHasher(1, 512, 512, num_threads)
+                order = [(v * 3 + phase + k) % 8 for k in range(frames_per_video)]
+                for k in order:
+                    h.hash_frame(blobs[k])
+                if h.finish().bytes != want_h[order].tobytes():
+                    errors.append((num_threads, v))
+                    return
+        except Exception as exc:  # noqa: BLE001 - reported below
+            errors.append((num_threads, repr(exc)))
+
+    ts = [threading.Thread(target=pusher, args=(2, 12, 150, 0)), threading.Thread(target=pusher, args=(8, 12, 150, 5))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
+def test_videohasher_two_hours_at_one_frame_per_second(gpu, hvd, oracle):
+    """7 200 frames through ONE VideoHasher(1, 512, 512, 0) -- the longest video the reference's defaults produce in two
+    hours (vpdqpy/vpdqpy.py:72-77: one frame per second); the ring had been tested with 1 000 frames at most."""
+    rgb = hvd.synth.frames_rgb(16, seed=53)
+    want_h, want_q = oracle.hash_frames(rgb)
+    n = 7200
+    order = (np.arange(n) * 7 + (np.arange(n) // 16)) % 16
+    h = hvd.VideoHasher(1, 512, 512, 0)
+    blobs = [f.tobytes() for f in rgb]
+    for k in order:
+        h.hash_frame(blobs[k])
+    got = h.finish()
+    keep = want_q[order] >= 31
+    assert len(got) == int(keep.sum()) and got.bytes == want_h[order][keep].tobytes()
