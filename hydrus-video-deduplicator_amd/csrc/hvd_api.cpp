@@ -1252,9 +1252,18 @@ int hvd_comm_init(const uint8_t id_bytes[HVD_UNIQUE_ID_BYTES], int rank, int wor
     memcpy(&id, id_bytes, sizeof id);
     // the two small words of the video search's agreement step are allocated here, so that nothing can fail between a
     // rank's decision to enter that collective and the collective itself
-    if (!g.x_cnt_in) HIP_TRY(hipMalloc(&g.x_cnt_in, 16));
-    if (!g.x_cnt_all) HIP_TRY(hipMalloc(&g.x_cnt_all, 16 * (size_t)world));
-    NCCL_TRY(ncclCommInitRank(&g.comm, world, id, rank));
+    // (sized for THIS world: a failed hvd_comm_init used to leave buffers of its own world behind, and a retry with a
+    // larger one all-gathered 16 * world bytes into them -- ADVICE r3)
+    free_exchange_buffers();
+    HIP_TRY(hipMalloc(&g.x_cnt_in, 16));
+    HIP_TRY(hipMalloc(&g.x_cnt_all, 16 * (size_t)world));
+    {
+        ncclResult_t r_ = ncclCommInitRank(&g.comm, world, id, rank);
+        if (r_ != ncclSuccess) {
+            free_exchange_buffers();
+            return fail(HVD_ERR_RCCL, "ncclCommInitRank(world=%d, rank=%d): %s", world, rank, ncclGetErrorString(r_));
+        }
+    }
     g.comm_ready = true;
     g.rank = rank;
     g.world = world;
@@ -1318,8 +1327,7 @@ int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_h
     if (count < 0 || cap < 0 || !out_total) return fail(HVD_ERR_ARG, "bad arguments");
     const int W = g.world;
     // 1) counts
-    if (!g.x_cnt_in) HIP_TRY(hipMalloc(&g.x_cnt_in, 8));
-    if (!g.x_cnt_all) HIP_TRY(hipMalloc(&g.x_cnt_all, 8 * (size_t)W));
+    if (!g.x_cnt_in || !g.x_cnt_all) return fail(HVD_ERR_STATE, "exchange words missing: hvd_comm_init() allocates them");
     unsigned long long c = (unsigned long long)count;
     HIP_TRY(hipMemcpyAsync(g.x_cnt_in, &c, 8, hipMemcpyHostToDevice, g.stream));
     NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 1, ncclUint64, g.comm, g.stream));

@@ -1040,11 +1040,11 @@ __device__ __forceinline__ void lds_store4_addtid(uint32_t base, float a, float 
         "ds_write_addtid_b32 %3 offset:%8"
         :
         : "v"(a), "v"(b), "v"(c), "v"(d), "s"(base), "n"(OFF0), "n"(OFF0 + STRIDE), "n"(OFF0 + 2 * STRIDE), "n"(OFF0 + 3 * STRIDE)
-        : "memory");
+        : "memory", "m0");  // (m0 is a register LLVM tracks: without the clobber a later use could assume its old value)
 }
 template <int OFF0>
 __device__ __forceinline__ void lds_store1_addtid(uint32_t base, float a) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(a), "s"(base), "n"(OFF0) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(a), "s"(base), "n"(OFF0) : "memory", "m0");
 }
 
 template <int CH>
@@ -1416,33 +1416,37 @@ bool pdq_dct_table_matches(const float* host_16x64) {
     return true;
 }
 
-// Work counters of k_pdq_hash64: a ring of self-cleaning slots (the last workgroup of a launch zeroes its slot), one per
-// launch in flight -- the streaming hasher runs up to three launches concurrently on its own streams.
-static unsigned int* g_hash_work = nullptr;
+// Work counters of k_pdq_hash64: a ring of slots, one per launch in flight -- the streaming hasher runs up to three launches
+// concurrently on its own streams. A slot is zeroed ON THE LAUNCH'S STREAM right in front of the launch (the
+// self-cleaning alone -- the launch's last draw zeroes its slot -- left a non-zero slot behind a faulted or aborted launch,
+// and the launch handed that slot 256 launches later skipped chunks silently; the one-off clearing also ran on the null
+// stream, unordered with the non-blocking streams the kernels run on). ~2 us per launch of >= 64 k frames.
+static std::atomic<unsigned int*> g_hash_work{nullptr};
 static std::atomic<unsigned int> g_hash_work_next{0};
 constexpr unsigned int kHashWorkSlots = 256;
 
 void pdq_release() {
-    if (g_hash_work) (void)hipFree(g_hash_work);
-    g_hash_work = nullptr;
+    unsigned int* p = g_hash_work.exchange(nullptr);
+    if (p) (void)hipFree(p);
 }
 
-// the next self-cleaning counter slot of the ring (allocated and zeroed on first use)
-static hipError_t work_slot(unsigned int** out) {
-    if (!g_hash_work) {
+// the next counter slot of the ring (allocated on first use), zeroed in stream order
+static hipError_t work_slot(unsigned int** out, hipStream_t s) {
+    unsigned int* base = g_hash_work.load(std::memory_order_acquire);
+    if (!base) {
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
-        if (!g_hash_work) {
+        base = g_hash_work.load(std::memory_order_acquire);
+        if (!base) {
             unsigned int* p = nullptr;
             hipError_t e = hipMalloc((void**)&p, kHashWorkSlots * 2 * sizeof(unsigned int));
             if (e != hipSuccess) return e;
-            e = hipMemset(p, 0, kHashWorkSlots * 2 * sizeof(unsigned int));
-            if (e != hipSuccess) return e;
-            g_hash_work = p;
+            g_hash_work.store(p, std::memory_order_release);
+            base = p;
         }
     }
-    *out = g_hash_work + 2u * (g_hash_work_next.fetch_add(1u) % kHashWorkSlots);
-    return hipSuccess;
+    *out = base + 2u * (g_hash_work_next.fetch_add(1u) % kHashWorkSlots);
+    return hipMemsetAsync(*out, 0, 2 * sizeof(unsigned int), s);
 }
 
 hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
@@ -1456,7 +1460,7 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
     const bool dynamic = g_pdq_dct_mode != 1 && n >= 65536;
     unsigned int* work = nullptr;
     if (dynamic) {
-        hipError_t e = work_slot(&work);
+        hipError_t e = work_slot(&work, s);
         if (e != hipSuccess) return e;
     }
     const int chunk = !dynamic ? 1 : n >= (1 << 20) ? 8 : n >= (1 << 18) ? 4 : 1;

@@ -72,10 +72,21 @@ def directed_distances(q_hits, t_hits, n_a, n_b, policy: str | None = None):
 
 
 class VpTreeManager:
+    # add_leaf's upkeep of the reference's on-disk tree walks from the root to a free slot: one SELECT and one distance per
+    # ancestor. Unrelated videos all sit at vPDQ distance 101, which the reference's rule ("inner iff distance <= radius",
+    # first radius = the first child's distance) turns into a CHAIN until its own maintain_tree rebalances -- which the
+    # facade never runs (its own search needs no tree). A walk is therefore cut off here (O(N) per ingested
+    # file, 5e9 distance calls for 100 k files): a balanced tree of 10^6 hashes is ~20 levels deep, so a longer path means
+    # the tree has degenerated; the leaf is then NOT inserted, `tree_incomplete` is set and a warning says what to do
+    # before the reference's tree is used again (its --clear-search-tree / regenerate_tree rebuilds it from
+    # shape_perceptual_hashes, where every hash still is).
+    MAX_TREE_WALK = 128
+
     def __init__(self, db, matcher=None, maintain_reference_tree: bool = True):
         self.db = db
         self._matcher = search if matcher is None else matcher  # tests inject a CPU stand-in
         self._maintain_tree = maintain_reference_tree
+        self.tree_incomplete = False  # a leaf was left out of shape_vptree because the walk exceeded MAX_TREE_WALK
         self._index = {}          # phash_id -> position
         self._phash_ids = []      # position -> phash_id
         self._blobs = []          # position -> bytes
@@ -133,7 +144,21 @@ class VpTreeManager:
         inner_side, outer_side = [], []
         flagged = False
         node = root[0] if root is not None else None
+        depth = 0
         while node is not None:
+            depth += 1
+            if depth > self.MAX_TREE_WALK:
+                # nothing has been written for this leaf yet (slots and populations are updated below the loop)
+                if not self.tree_incomplete:
+                    import warnings
+
+                    warnings.warn(
+                        f"shape_vptree is more than {self.MAX_TREE_WALK} levels deep (degenerate until the reference's "
+                        "maintain_tree runs): new hashes are no longer inserted into it; run the reference's "
+                        "--clear-search-tree (regenerate_tree) before using its tree on this database again",
+                        RuntimeWarning, stacklevel=3)
+                self.tree_incomplete = True
+                return
             row = self.db.execute(
                 "SELECT phash, radius, inner_id, inner_population, outer_id, outer_population FROM shape_perceptual_hashes "
                 "NATURAL JOIN shape_vptree WHERE phash_id = ?;", (node,)).fetchone()
@@ -275,46 +300,60 @@ class VpTreeManager:
             self._conn = getattr(self.db, "conn", None) or self.db
         return self._conn
 
+    # What tells that shape_perceptual_hash_map changed (the first version counted CHANGES, and a counter that
+    # is rolled back together with the change it counted reads the same after "insert, look, ROLLBACK, insert another row"):
+    # the table's row count and a checksum of its rows, kept current by TEMP triggers -- they live in this connection's temp
+    # schema, nothing is written to the user's file, and a ROLLBACK takes them back together with the rows they describe.
+    # Commits by OTHER connections do not fire them; SQLite's data_version (O(1), read at every look) reports those, and
+    # the two numbers are then taken from the table again.
+    _ROW_SUM = "{0}.phash_id * 1000003 + {0}.hash_id"
     _VERSION_SQL = (
-        "CREATE TEMP TABLE IF NOT EXISTS hvd_amd_map_version ( v INTEGER )",
-        "INSERT INTO temp.hvd_amd_map_version SELECT 0 WHERE NOT EXISTS ( SELECT 1 FROM temp.hvd_amd_map_version )",
+        "CREATE TEMP TABLE IF NOT EXISTS hvd_amd_map_state ( c INTEGER, s INTEGER )",
         "CREATE TEMP TRIGGER IF NOT EXISTS hvd_amd_map_ins AFTER INSERT ON main.shape_perceptual_hash_map "
-        "BEGIN UPDATE hvd_amd_map_version SET v = v + 1; END",
+        "BEGIN UPDATE hvd_amd_map_state SET c = c + 1, s = s + " + _ROW_SUM.format("NEW") + "; END",
         "CREATE TEMP TRIGGER IF NOT EXISTS hvd_amd_map_del AFTER DELETE ON main.shape_perceptual_hash_map "
-        "BEGIN UPDATE hvd_amd_map_version SET v = v + 1; END",
+        "BEGIN UPDATE hvd_amd_map_state SET c = c - 1, s = s - (" + _ROW_SUM.format("OLD") + "); END",
         "CREATE TEMP TRIGGER IF NOT EXISTS hvd_amd_map_upd AFTER UPDATE ON main.shape_perceptual_hash_map "
-        "BEGIN UPDATE hvd_amd_map_version SET v = v + 1; END",
+        "BEGIN UPDATE hvd_amd_map_state SET s = s - (" + _ROW_SUM.format("OLD") + ") + " + _ROW_SUM.format("NEW") + "; END",
+    )
+    _RESYNC_SQL = (
+        "DELETE FROM temp.hvd_amd_map_state",
+        "INSERT INTO temp.hvd_amd_map_state SELECT COUNT(*), COALESCE(SUM(" + _ROW_SUM.format("m") + "), 0) "
+        "FROM main.shape_perceptual_hash_map AS m",
     )
 
-    def _map_version(self):
-        """A value that changes whenever shape_perceptual_hash_map does: a counter kept by TEMP triggers (they live in
-        this connection's temp schema -- nothing is written to the user's file) for changes made through this connection,
-        plus SQLite's data_version for commits by other connections. Fallback where triggers cannot be created: the
-        table's largest rowid (misses a bare DELETE)."""
+    def _map_state(self, resync: bool):
+        """(row count, row checksum) of shape_perceptual_hash_map from the trigger-kept state, or None where the triggers
+        cannot be created (a read-only connection: nothing can change through it, data_version alone decides)."""
         if self._map_triggers is None:
             try:
                 for stmt in self._VERSION_SQL:
                     self.db.execute(stmt)
                 self._map_triggers = True
+                resync = True
             except Exception:  # noqa: BLE001 - e.g. a read-only connection
                 self._map_triggers = False
-        if self._map_triggers:
-            v = self.db.execute("SELECT v FROM temp.hvd_amd_map_version").fetchone()
-        else:
-            v = self.db.execute("SELECT MAX(rowid) FROM shape_perceptual_hash_map").fetchone()
-        return v[0], self.db.execute("PRAGMA data_version").fetchone()[0]
+        if not self._map_triggers:
+            return None
+        if resync or self.db.execute("SELECT COUNT(*) FROM temp.hvd_amd_map_state").fetchone()[0] != 1:
+            for stmt in self._RESYNC_SQL:
+                self.db.execute(stmt)
+        return tuple(self.db.execute("SELECT c, s FROM temp.hvd_amd_map_state").fetchone())
 
     def _map_fresh(self) -> None:
-        """Make the in-memory copy of shape_perceptual_hash_map current. Nothing changed on this connection since the
-        last look (its own change counter, no SQL) -> done. Otherwise -- the search loop itself updates
-        shape_search_cache after every file, dedup.py:488-491 -- two O(1) statements decide."""
+        """Make the in-memory copy of shape_perceptual_hash_map current. data_version is read at EVERY look (another
+        connection's commit changes nothing on this one); nothing changed on this connection either (its own change
+        counter, no SQL) -> done. Otherwise -- the search loop itself updates shape_search_cache after every file,
+        dedup.py:488-491 -- one O(1) statement decides."""
+        dv = self.db.execute("PRAGMA data_version").fetchone()[0]
         changes = getattr(self._connection(), "total_changes", None)
-        if changes is not None and changes == self._map_checked_at and self._map_token is not None:
+        if self._map_token is not None and dv == self._map_token[0] and changes is not None and changes == self._map_checked_at:
             return
-        token = self._map_version()
-        # (creating the triggers / bumping the counter counts as a change: read the counter after the statements)
+        foreign_commit = self._map_token is None or dv != self._map_token[0]
+        token = (dv, self._map_state(resync=foreign_commit))
+        # (creating the triggers / re-synchronising the state counts as a change: read the counter after the statements)
         self._map_checked_at = getattr(self._connection(), "total_changes", None)
-        if token == self._map_token:
+        if token == self._map_token and not foreign_commit:
             return
         files_of, phash_of = {}, {}
         for phash_id, hash_id in self.db.execute("SELECT phash_id, hash_id FROM shape_perceptual_hash_map ORDER BY phash_id, hash_id").fetchall():

@@ -215,13 +215,14 @@ def _tree_rows(conn):
         "SELECT phash_id, parent_id, radius, inner_id, inner_population, outer_id, outer_population FROM shape_vptree")}
 
 
-def _check_tree_is_valid(conn, dist):
-    """Every perceptual hash is a node; exactly one root; every node hangs on the side of each ancestor that its distance
+def _check_tree_is_valid(conn, dist, complete=True):
+    """Every perceptual hash is a node (complete=False: every node is a perceptual hash -- a tree that add_leaf stopped
+    extending at MAX_TREE_WALK); exactly one root; every node hangs on the side of each ancestor that its distance
     to that ancestor says (inner iff <= radius); populations count the descendants. This is what the reference's search
     (db/vptree.py:707-777) relies on."""
     rows = _tree_rows(conn)
     blobs = {pid: bytes(b) for pid, b in conn.execute("SELECT phash_id, phash FROM shape_perceptual_hashes")}
-    assert set(rows) == set(blobs)
+    assert set(rows) == set(blobs) if complete else set(rows) <= set(blobs)
     roots = [p for p, r in rows.items() if r[0] is None]
     assert len(roots) == 1
 
@@ -438,3 +439,89 @@ def test_radius_101_returns_every_file_like_a_tree_that_prunes_nothing(hvd, orac
             want[o] = min(d, want.get(o, 999))
         assert got == want
     assert len(tree.search_file(1, 100)) < 21
+
+
+def test_add_leaf_cost_is_bounded_on_a_degenerate_tree(hvd, oracle):
+    """unrelated videos all sit at distance 101, which the reference's insertion rule turns into a chain
+    (its own maintain_tree rebalances; the facade's is a no-op), so add_leaf's walk grew by one SELECT + one distance per
+    file already ingested. The walk is cut off at MAX_TREE_WALK: the leaf is left out of shape_vptree, the instance says
+    so, the facade's own search is unaffected (it never reads the tree)."""
+    import sqlite3
+    import warnings
+
+    class Counting(OracleMatcher):
+        calls = 0
+
+        def calculate_distance(self, a, b):
+            Counting.calls += 1
+            return super().calculate_distance(a, b)
+
+    m = Counting(oracle)
+    rng = np.random.default_rng(7)
+    n = 400
+    blobs = [rng.integers(0, 256, 32 * 4, dtype=np.uint8).tobytes() for _ in range(n)]  # unrelated: every distance is 101
+    conn = sqlite3.connect(":memory:")
+    for stmt in SCHEMA:
+        conn.execute(stmt)
+    for k, b in enumerate(blobs):
+        conn.execute("INSERT INTO phashed_file_queue VALUES (?, ?)", (f"{k:064x}", b))
+    incomplete = []
+
+    class PerFile:  # the reference's pattern: one manager per inserted file (db/DedupeDB.py:303-304)
+        def add_leaf(self, pid, blob):
+            t = hvd.vptree.VpTreeManager(conn, matcher=m)
+            t.add_leaf(pid, blob)
+            incomplete.append(t.tree_incomplete)
+
+    cap = hvd.vptree.VpTreeManager.MAX_TREE_WALK
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert hvd.sqlite_adapter.ingest_phashed_file_queue(conn, tree=PerFile()) == n
+    assert any("shape_vptree" in str(x.message) for x in w)
+    assert Counting.calls <= n * cap  # bounded per file (it was n * (n - 1) / 2 = 79 800 without the cap)
+    in_tree = conn.execute("SELECT COUNT(*) FROM shape_vptree").fetchone()[0]
+    assert cap <= in_tree <= cap + 1 and incomplete.count(True) == n - in_tree
+    _check_tree_is_valid(conn, m.calculate_distance, complete=False)  # what IS in the tree is still a valid tree
+    # the facade's search sees every file regardless
+    tree = hvd.vptree.VpTreeManager(conn, matcher=m)
+    res = tree.search_file(4, 101)  # radius 101 = "similarity below 1 %": every file, the capped-out ones included
+    assert res[0] == (4, 0) and {h for h, _ in res} == set(range(1, n + 1))
+
+
+def test_phash_map_cache_survives_rollbacks_and_foreign_commits(hvd, oracle, tmp_path):
+    """the cached copy of shape_perceptual_hash_map was keyed on a CHANGE counter that a ROLLBACK takes
+    back together with the change -- insert, look, roll back, insert a different row: same key, stale map -- and commits by
+    another connection were only noticed when this connection had changed something too."""
+    import sqlite3
+
+    path = str(tmp_path / "videohashes.sqlite")
+    conn = sqlite3.connect(path)
+    for stmt in SCHEMA:
+        conn.execute(stmt)
+    blob = np.arange(64, dtype=np.uint8).tobytes()
+    conn.execute("INSERT INTO shape_perceptual_hashes VALUES (1, ?)", (blob,))
+    for h in (1, 2, 3):
+        conn.execute("INSERT INTO files VALUES (?, ?)", (h, f"{h:064x}"))
+    conn.execute("INSERT INTO shape_perceptual_hash_map VALUES (1, 1)")
+    conn.commit()
+    tree = hvd.vptree.VpTreeManager(conn, matcher=OracleMatcher(oracle))
+    assert tree.search_file(1, 0) == [(1, 0)]
+    # same connection: insert, look, ROLLBACK, insert a different row
+    conn.execute("INSERT INTO shape_perceptual_hash_map VALUES (1, 2)")
+    assert set(tree.search_file(1, 0)) == {(1, 0), (2, 0)}
+    conn.rollback()
+    conn.execute("INSERT INTO shape_perceptual_hash_map VALUES (1, 3)")
+    assert set(tree.search_file(1, 0)) == {(1, 0), (3, 0)}
+    conn.commit()
+    # another connection commits while this one changes nothing
+    other = sqlite3.connect(path)
+    other.execute("INSERT INTO shape_perceptual_hash_map VALUES (1, 2)")
+    other.commit()
+    assert set(tree.search_file(1, 0)) == {(1, 0), (2, 0), (3, 0)}
+    conn.commit()  # (the look re-synchronised the TEMP state inside this connection's implicit transaction, which holds a
+    #                read lock on the file until the caller's next commit -- dedup.py:491 commits after every file)
+    other.execute("DELETE FROM shape_perceptual_hash_map WHERE hash_id = 3")
+    other.commit()
+    other.close()
+    assert set(tree.search_file(1, 0)) == {(1, 0), (2, 0)}
+    assert set(tree.search_file(1, 0)) == {(1, 0), (2, 0)}
