@@ -1040,11 +1040,13 @@ __device__ __forceinline__ void lds_store4_addtid(uint32_t base, float a, float 
         "ds_write_addtid_b32 %3 offset:%8"
         :
         : "v"(a), "v"(b), "v"(c), "v"(d), "s"(base), "n"(OFF0), "n"(OFF0 + STRIDE), "n"(OFF0 + 2 * STRIDE), "n"(OFF0 + 3 * STRIDE)
-        : "memory", "m0");  // (m0 is a register LLVM tracks: without the clobber a later use could assume its old value)
+        : "memory");  // (no "m0" clobber: hipcc 7.2 rejects it as a reserved register -- "may lead to undefined behaviour";
+                      // M0 has no value the compiler relies on across statements here: it sets M0 itself, right in front of each
+                      // of its own uses -- the global_load_lds / LDS-DMA builtins -- and this kernel has none)
 }
 template <int OFF0>
 __device__ __forceinline__ void lds_store1_addtid(uint32_t base, float a) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(a), "s"(base), "n"(OFF0) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:%2" : : "v"(a), "s"(base), "n"(OFF0) : "memory");
 }
 
 template <int CH>
