@@ -32,6 +32,11 @@ SIGNATURES = {
     "hvd_abi_version": (_int, []),
     "hvd_device_count": (_int, [C.POINTER(_int)]),
     "hvd_init": (_int, [_int]),
+    "hvd_init_devices": (_int, [C.POINTER(C.c_int), _int]),
+    "hvd_context_count": (_int, [C.POINTER(C.c_int)]),
+    "hvd_set_context": (_int, [_int]),
+    "hvd_get_context": (_int, []),
+    "hvd_group_exchange": (_int, []),
     "hvd_shutdown": (_int, []),
     "hvd_last_error": (_int, [C.c_char_p, _sz]),
     "hvd_dct_matrix": (_int, [_vp]),
@@ -139,15 +144,47 @@ def device_count() -> int:
 
 
 def init(device: int | None = None) -> C.CDLL:
-    """Bind this process to one GPU (default: $HVD_DEVICE, else $LOCAL_RANK, else 0)."""
+    """Bind this process to one GPU (default: $HVD_DEVICE, else $LOCAL_RANK, else the first of $HVD_DEVICES, else 0).
+    With HVD_DEVICES=0,1,2,... the library turns this into a device GROUP (hvd_init_devices): the host-buffer entry points
+    -- and with them the search, the VpTreeManager facade and the SQLite adapter -- then shard over all listed GPUs inside
+    this one process."""
     global _inited_device
     lib = load()
     if device is None:
-        device = int(os.environ.get("HVD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        first = os.environ.get("HVD_DEVICES", "0").split(",")[0].strip() or "0"
+        device = int(os.environ.get("HVD_DEVICE", os.environ.get("LOCAL_RANK", first)))
     if _inited_device != device:
         check(lib.hvd_init(device))
         _inited_device = device
     return lib
+
+
+def init_devices(devices) -> C.CDLL:
+    """Bind this process to a group of GPUs, one context per listed device (include/hvd_mi355x.h: hvd_init_devices). A
+    device may be listed twice (two contexts on one GPU; the exchange steps then go through host memory)."""
+    global _inited_device
+    lib = load()
+    devs = [int(d) for d in devices]
+    arr = (C.c_int * len(devs))(*devs)
+    check(lib.hvd_init_devices(arr, len(devs)))
+    _inited_device = devs[0]
+    return lib
+
+
+def context_count() -> int:
+    n = C.c_int(0)
+    check(load().hvd_context_count(C.byref(n)))
+    return n.value
+
+
+def set_context(index: int) -> None:
+    """The calling THREAD's current context (and HIP device) from now on; device buffers belong to the context they were
+    allocated on."""
+    check(load().hvd_set_context(int(index)))
+
+
+def group_exchange() -> str:
+    return {0: "none", 1: "rccl", 2: "host"}[load().hvd_group_exchange()]
 
 
 def ensure() -> C.CDLL:

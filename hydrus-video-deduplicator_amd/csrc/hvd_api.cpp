@@ -1,9 +1,13 @@
 // hvd_api.cpp -- host side of the C-ABI declared in include/hvd_mi355x.h.
 //
-// One process drives one MI355X (hvd_init(device)); all kernels go to one library
-// stream. No CPU fallback exists anywhere in this file: every compute entry point
-// needs an initialised device and fails with HVD_ERR_STATE / HVD_ERR_NO_DEVICE
-// otherwise.
+// A process drives one MI355X (hvd_init(device)) or a GROUP of them (hvd_init_devices / HVD_DEVICES): one context per
+// listed device -- stream, timer events, grow-only scratch pool, select/context words of the all-pairs kernel, RCCL
+// communicator -- the "ranks" of the tile-cyclic sharding inside one process (the reference is one process:
+// entrypoint.py:235 -> dedup.py:213). Every entry point works on the calling thread's CURRENT context (context 0 unless
+// hvd_set_context says otherwise); the host-buffer entry points fan out over all contexts of the group by themselves, one
+// host thread per context, so that whatever binds this library uses every configured GPU without a launcher. No CPU
+// fallback exists anywhere in this file: every compute entry point needs an initialised device and fails with
+// HVD_ERR_STATE / HVD_ERR_NO_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -13,7 +17,11 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "hvd_kernels.h"
@@ -46,6 +54,8 @@ int fail(int code, const char* fmt, ...) {
 struct Ctx {
     bool ready = false;
     int device = -1;
+    int id = 0;               // index in the group (= rank of the in-process sharding)
+    bool host_exchange = false;  // group without RCCL (a device listed twice): exchange steps go through host memory
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float* d_dct = nullptr;
@@ -83,8 +93,36 @@ struct Ctx {
     int v_force_slots_log2 = 0;       // hvd_debug_set("vmatch_slots_log2"): start the tables this small (tests the regrowth)
     std::recursive_mutex h_mu;
 };
-Ctx g;
+constexpr int kMaxCtx = 16;
+Ctx g_ctx[kMaxCtx];
+int g_nctx = 0;                 // contexts of the group (0 before hvd_init / hvd_init_devices)
+bool g_group_rccl = false;      // the group's contexts hold communicators of one ncclCommInitAll
+thread_local int t_ctx = 0;     // the calling thread's current context
+#define g (g_ctx[t_ctx])
 std::mutex g_mu;
+
+// Rendezvous of the group's worker threads (one per context) for the exchange steps that have no RCCL underneath: a group
+// that lists one device twice (RCCL refuses duplicate devices; tests/test_gpu_round4.py), where the ranks' candidates and
+// keys meet in host memory instead. A plain generation barrier plus a slot per rank.
+struct HostExchange {
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long gen = 0;
+    std::vector<std::vector<unsigned long long>> words;  // one vector per rank
+    void barrier(int n) {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long long my = gen;
+        if (++arrived == n) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != my; });
+        }
+    }
+};
+HostExchange g_hx;
 
 // pdqhashing.cpp fill_dct_matrix_64_cached: float scale * double cos, rounded once.
 void fill_dct(float* out) {
@@ -107,6 +145,7 @@ struct DevBuf {
 };
 
 int need_ready() {
+    if (t_ctx >= g_nctx) t_ctx = 0;  // (a thread that selected a context of an earlier, larger group)
     if (!g.ready) return fail(HVD_ERR_STATE, "hvd_init() has not been called (no CPU fallback exists)");
     // HIP's current device is per host thread; the reference calls this path from the main thread or
     // from a QThread worker (gui/gui.py:195-237), so every entry re-asserts the bound device.
@@ -136,6 +175,8 @@ const float* api_dct_device() {
     return g.d_dct;
 }
 int api_bind_device() { return need_ready(); }
+int api_context() { return t_ctx; }
+void api_set_context(int idx) { t_ctx = idx; }
 }  // namespace hvd
 
 extern "C" {
@@ -172,29 +213,22 @@ int hvd_dct_matrix_libm(float* out) {
     return HVD_OK;
 }
 
-int hvd_init(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g.ready) {
-        if (g.device == device) return HVD_OK;
-        return fail(HVD_ERR_STATE, "already bound to device %d (one process per GPU)", g.device);
-    }
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-        (void)hipGetLastError();
-        return fail(HVD_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
-    }
-    if (device < 0 || device >= n) return fail(HVD_ERR_ARG, "device %d out of range [0,%d)", device, n);
+}  // extern "C" (context management helpers have C++ linkage)
+
+namespace {
+
+// Bring context `idx` up on HIP device `device` (the caller holds g_mu and has checked the device list).
+int init_context(int idx, int device) {
+    const int saved = t_ctx;
+    t_ctx = idx;
+    struct Restore {
+        int v;
+        ~Restore() { t_ctx = v; }
+    } restore{saved};
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(HVD_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
-                    prop.gcnArchName);
-    int dct_mode = hvd::g_pdq_dct_mode;
-    if (const char* m = getenv("HVD_PDQ_DCT_MODE")) {  // same switch as hvd_set_pdq_dct_mode(); checked before any resource exists
-        if (!strcmp(m, "fma") || !strcmp(m, "1")) dct_mode = HVD_DCT_FMA;
-        else if (!strcmp(m, "strict") || !strcmp(m, "0") || !*m) dct_mode = HVD_DCT_STRICT;
-        else return fail(HVD_ERR_ARG, "HVD_PDQ_DCT_MODE=%s: expected strict or fma", m);
-    }
+        return fail(HVD_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     HIP_TRY(hipSetDevice(device));
     // The DCT matrix is a constant of the algorithm: the table compiled into the kernels (csrc/dct_table.inc, generated
     // once by scripts/gen_dct_table.py) is authoritative for the literal AND the operand forms of the hash kernel, so the
@@ -215,35 +249,188 @@ int hvd_init(int device) {
         g.stream = nullptr;
         return fail(HVD_ERR_HIP, "hvd_init(%d): %s", device, hipGetErrorString(e));
     }
-    hvd::g_pdq_dct_mode = dct_mode;
     g.device = device;
+    g.id = idx;
     g.ready = true;
     return HVD_OK;
 }
 
+void shutdown_context(int idx) {
+    const int saved = t_ctx;
+    t_ctx = idx;
+    if (g.ready) {
+        (void)hipSetDevice(g.device);
+        (void)hipStreamSynchronize(g.stream);
+        if (g.comm_ready) {
+            free_exchange_buffers();
+            (void)ncclCommDestroy(g.comm);
+            g.comm_ready = false;
+        }
+        (void)hipFree(g.d_dct);
+        (void)hipEventDestroy(g.ev0);
+        (void)hipEventDestroy(g.ev1);
+        (void)hipStreamDestroy(g.stream);
+        for (void** p : {&g.m_a, &g.m_b, &g.m_f, &g.m_o})
+            if (*p) (void)hipFree(*p);
+        for (void* p : g.scr)
+            if (p) (void)hipFree(p);
+        if (g.m_pin) (void)hipHostFree(g.m_pin);
+        g.~Ctx();
+        new (&g) Ctx();
+    }
+    t_ctx = saved;
+}
+
+int parse_dct_mode(int* out) {
+    *out = hvd::g_pdq_dct_mode;
+    if (const char* m = getenv("HVD_PDQ_DCT_MODE")) {  // same switch as hvd_set_pdq_dct_mode(); checked before any resource exists
+        if (!strcmp(m, "fma") || !strcmp(m, "1")) *out = HVD_DCT_FMA;
+        else if (!strcmp(m, "strict") || !strcmp(m, "0") || !*m) *out = HVD_DCT_STRICT;
+        else return fail(HVD_ERR_ARG, "HVD_PDQ_DCT_MODE=%s: expected strict or fma", m);
+    }
+    return HVD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hvd_init_devices(const int* devices, int n_devices) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!devices || n_devices < 1 || n_devices > kMaxCtx)
+        return fail(HVD_ERR_ARG, "hvd_init_devices: need 1..%d devices", kMaxCtx);
+    if (g_nctx > 0) {
+        bool same = g_nctx == n_devices;
+        for (int i = 0; same && i < n_devices; ++i) same = g_ctx[i].device == devices[i];
+        if (same) return HVD_OK;
+        return fail(HVD_ERR_STATE, "already bound to %d device(s) starting with device %d; hvd_shutdown() first", g_nctx,
+                    g_ctx[0].device);
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(HVD_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    }
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i) {
+        if (devices[i] < 0 || devices[i] >= n) return fail(HVD_ERR_ARG, "device %d out of range [0,%d)", devices[i], n);
+        for (int k = 0; k < i; ++k) distinct = distinct && devices[k] != devices[i];
+    }
+    int dct_mode = 0;
+    if (int rc = parse_dct_mode(&dct_mode)) return rc;
+    for (int i = 0; i < n_devices; ++i)
+        if (int rc = init_context(i, devices[i])) {
+            for (int k = 0; k < i; ++k) shutdown_context(k);
+            return rc;
+        }
+    hvd::g_pdq_dct_mode = dct_mode;
+    g_nctx = n_devices;
+    g_group_rccl = false;
+    g_hx.words.assign((size_t)n_devices, {});
+    if (n_devices > 1) {
+        // The exchange steps of the sharded searches: RCCL all-gathers between the group's devices (ncclCommInitAll: one
+        // process, one communicator per device). RCCL refuses a device that is listed twice -- such a group (a test
+        // configuration: two contexts on one GPU) exchanges through host memory instead, and so does a group whose
+        // communicators cannot be created; hvd_group_exchange() says which.
+        bool rccl = distinct && !getenv("HVD_GROUP_NO_RCCL");
+        if (rccl) {
+            ncclComm_t comms[kMaxCtx];
+            ncclResult_t r = ncclCommInitAll(comms, n_devices, devices);
+            if (r == ncclSuccess) {
+                const int saved = t_ctx;
+                for (int i = 0; i < n_devices && rccl; ++i) {
+                    t_ctx = i;
+                    (void)hipSetDevice(g.device);
+                    g.comm = comms[i];
+                    g.rank = i;
+                    g.world = n_devices;
+                    if (hipMalloc(&g.x_cnt_in, 16) != hipSuccess || hipMalloc(&g.x_cnt_all, 16 * (size_t)n_devices) != hipSuccess) rccl = false;
+                    g.comm_ready = true;
+                }
+                t_ctx = saved;
+            } else {
+                rccl = false;
+            }
+            if (!rccl)
+                for (int i = 0; i < n_devices; ++i)
+                    if (g_ctx[i].comm_ready) {
+                        t_ctx = i;
+                        free_exchange_buffers();
+                        (void)ncclCommAbort(g.comm);
+                        g.comm_ready = false;
+                        t_ctx = 0;
+                    }
+        }
+        g_group_rccl = rccl;
+        for (int i = 0; i < n_devices; ++i) {
+            g_ctx[i].host_exchange = !rccl;
+            g_ctx[i].rank = i;
+            g_ctx[i].world = n_devices;
+        }
+    }
+    (void)hipSetDevice(g_ctx[0].device);
+    return HVD_OK;
+}
+
+int hvd_init(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_nctx > 0) {
+            if (g_nctx == 1 && g_ctx[0].device == device) return HVD_OK;
+            if (g_nctx > 1 && g_ctx[0].device == device) return HVD_OK;  // a group whose first context is this device
+            return fail(HVD_ERR_STATE, "already bound to device %d (hvd_shutdown() first, or list the devices: hvd_init_devices)",
+                        g_ctx[0].device);
+        }
+    }
+    // HVD_DEVICES=0,1,2,3 turns the one-device initialisation every binding performs into a group: the drop-in surfaces
+    // (search, VpTreeManager facade, SQLite adapter, pipeline) then shard over all listed GPUs inside this process.
+    if (const char* env = getenv("HVD_DEVICES")) {
+        int devs[kMaxCtx], n = 0;
+        const char* p = env;
+        while (*p && n < kMaxCtx) {
+            char* end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) return fail(HVD_ERR_ARG, "HVD_DEVICES=%s: expected a comma-separated list of device numbers", env);
+            devs[n++] = (int)v;
+            p = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') return fail(HVD_ERR_ARG, "HVD_DEVICES=%s: expected a comma-separated list of device numbers", env);
+        }
+        if (n > 1 || (n == 1 && devs[0] != device)) {
+            if (n >= 1 && devs[0] != device)
+                return fail(HVD_ERR_ARG, "hvd_init(%d) with HVD_DEVICES=%s: the list must start with the device asked for", device, env);
+            return hvd_init_devices(devs, n);
+        }
+    }
+    return hvd_init_devices(&device, 1);
+}
+
+int hvd_context_count(int* out_n) {
+    if (!out_n) return fail(HVD_ERR_ARG, "out_n is NULL");
+    *out_n = g_nctx;
+    return HVD_OK;
+}
+
+int hvd_set_context(int index) {
+    if (index < 0 || index >= (g_nctx > 0 ? g_nctx : 1)) return fail(HVD_ERR_ARG, "context %d out of range [0,%d)", index, g_nctx);
+    t_ctx = index;
+    if (g.ready) HIP_TRY(hipSetDevice(g.device));
+    return HVD_OK;
+}
+
+int hvd_get_context(void) { return t_ctx; }
+
+int hvd_group_exchange(void) { return g_nctx <= 1 ? 0 : g_group_rccl ? 1 : 2; }
+
 int hvd_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.ready) return HVD_OK;
-    (void)hipStreamSynchronize(g.stream);
-    if (g.comm_ready) {
-        free_exchange_buffers();
-        (void)ncclCommDestroy(g.comm);
-        g.comm_ready = false;
-    }
-    (void)hipFree(g.d_dct);
-    (void)hipEventDestroy(g.ev0);
-    (void)hipEventDestroy(g.ev1);
-    (void)hipStreamDestroy(g.stream);
-    for (void** p : {&g.m_a, &g.m_b, &g.m_f, &g.m_o})
-        if (*p) (void)hipFree(*p);
-    for (void* p : g.scr)
-        if (p) (void)hipFree(p);
-    if (g.m_pin) (void)hipHostFree(g.m_pin);
+    if (g_nctx == 0) return HVD_OK;
+    for (int i = 0; i < g_nctx; ++i) shutdown_context(i);
     hvd::stream_release_cache();
     hvd::mfma_release();
     hvd::pdq_release();
-    g.~Ctx();
-    new (&g) Ctx();
+    g_nctx = 0;
+    g_group_rccl = false;
+    t_ctx = 0;
     return HVD_OK;
 }
 
@@ -416,7 +603,7 @@ int hvd_debug_get(const char* key, int* out_value) {
     for (int k = 0; k < 4; ++k)
         if (strcmp(key, keys[k]) == 0) {
             uint32_t* sel = nullptr;
-            HIP_TRY(hvd::mfma_select_buffer(&sel));
+            HIP_TRY(hvd::mfma_select_buffer(t_ctx, &sel));
             uint32_t v[4] = {0, 0, 0, 0};
             HIP_TRY(hipMemcpyAsync(v, sel, 16, hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipStreamSynchronize(g.stream));
@@ -427,7 +614,7 @@ int hvd_debug_get(const char* key, int* out_value) {
         const int k = atoi(key + 10);
         if (k < 0 || k > 15) return fail(HVD_ERR_ARG, "mfma_qstat0..15");
         uint32_t* sel = nullptr;
-        HIP_TRY(hvd::mfma_select_buffer(&sel));
+        HIP_TRY(hvd::mfma_select_buffer(t_ctx, &sel));
         unsigned long long v = 0;
         HIP_TRY(hipMemcpyAsync(&v, sel + 128 + 2 * k, 8, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipMemsetAsync(sel + 128 + 2 * k, 0, 8, g.stream));
@@ -536,6 +723,7 @@ int hvd_dev_allpairs_hamming256_mfma(const void* d_db, const void* d_img, int64_
     a.d_count = (unsigned long long*)d_count;
     a.variant = variant;
     a.col_chunk = 0;
+    a.ctx_id = t_ctx;
     hipError_t e = hvd::launch_allpairs_mfma(a, d_img, g.stream);
     if (e != hipSuccess) return fail(HVD_ERR_HIP, "launch_allpairs_mfma(variant=%d): %s", variant, hipGetErrorString(e));
     return HVD_OK;
@@ -562,6 +750,7 @@ int hvd_dev_allpairs_hamming256(const void* d_db, int64_t n, const void* d_group
     a.d_count = (unsigned long long*)d_count;
     a.variant = variant;
     a.col_chunk = 0;
+    a.ctx_id = t_ctx;
     hipError_t e = hvd::launch_allpairs(a, g.stream);
     if (e != hipSuccess) return fail(HVD_ERR_HIP, "launch_allpairs(variant=%d): %s", variant, hipGetErrorString(e));
     return HVD_OK;
@@ -601,12 +790,73 @@ int hvd_dev_cross_hamming256_mfma(const void* d_img_q, int64_t nq, const void* d
     a.d_count = (unsigned long long*)d_count;
     a.variant = HVD_DEFAULT_VARIANT;
     a.col_chunk = 0;
+    a.ctx_id = t_ctx;
     hipError_t e = hvd::launch_cross_mfma(a, d_img_q, (uint32_t)nq, d_img_t, (const int32_t*)d_group_t, g.stream);
     if (e != hipSuccess) return fail(HVD_ERR_HIP, "launch_cross_mfma: %s", hipGetErrorString(e));
     return HVD_OK;
 }
 
 /* ------------------------------------------------- host-buffer entry points -- */
+
+}  // extern "C"
+
+namespace {
+// Run fn(rank) on every context of the group, one host thread per context (the caller's thread takes context 0; a group of
+// one runs inline). Returns the first failure's code with its message in the calling thread's error buffer. Only ONE fan-out
+// runs at a time (the host-memory exchange has one set of slots, and two concurrent fan-outs would only take turns on the
+// devices anyway).
+std::mutex g_group_mu;
+int run_on_group(const std::function<int(int)>& fn) {
+    const int n = g_nctx;
+    if (n <= 1) return fn(0);
+    std::lock_guard<std::mutex> lk(g_group_mu);
+    std::vector<int> rc((size_t)n, HVD_OK);
+    std::vector<std::string> msg((size_t)n);
+    auto body = [&](int i) {
+        t_ctx = i;
+        rc[(size_t)i] = need_ready();
+        if (rc[(size_t)i] == HVD_OK) rc[(size_t)i] = fn(i);
+        if (rc[(size_t)i] != HVD_OK) msg[(size_t)i] = g_err;
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n; ++i) th.emplace_back(body, i);
+    const int saved = t_ctx;
+    body(0);
+    t_ctx = saved;
+    for (std::thread& t : th) t.join();
+    (void)need_ready();
+    for (int i = 0; i < n; ++i)
+        if (rc[(size_t)i] != HVD_OK) {
+            snprintf(g_err, sizeof g_err, "%s", msg[(size_t)i].c_str());
+            return rc[(size_t)i];
+        }
+    return HVD_OK;
+}
+
+// all-gather of two words per rank inside a sharded group call (RCCL or host memory); every context's thread calls it
+int exchange_words(const unsigned long long word[2], std::vector<unsigned long long>& all) {
+    const int W = g.world;
+    all.assign(2 * (size_t)W, 0ull);
+    if (g.host_exchange) {
+        g_hx.barrier(W);
+        g_hx.words[(size_t)g.rank].assign(word, word + 2);
+        g_hx.barrier(W);
+        for (int r = 0; r < W; ++r) {
+            all[2 * (size_t)r] = g_hx.words[(size_t)r][0];
+            all[2 * (size_t)r + 1] = g_hx.words[(size_t)r][1];
+        }
+        return HVD_OK;
+    }
+    if (!g.comm_ready) return fail(HVD_ERR_STATE, "no communicator on context %d", g.id);
+    HIP_TRY(hipMemcpyAsync(g.x_cnt_in, word, 16, hipMemcpyHostToDevice, g.stream));
+    NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 2, ncclUint64, g.comm, g.stream));
+    HIP_TRY(hipMemcpyAsync(all.data(), g.x_cnt_all, 16 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return HVD_OK;
+}
+}  // namespace
+
+extern "C" {
 
 static int scratch(Ctx::Scr id, size_t need, void** out) {
     if (int rc = grow(&g.scr[id], &g.scr_cap[id], need ? need : 1)) return rc;
@@ -651,48 +901,92 @@ static int hash_frames_host(const uint8_t* frames, int64_t n, int h, int w, int 
     return HVD_OK;
 }
 
+// frames are independent: a group hashes contiguous ranges of them, one per context, no exchange
+static int hash_frames_group(const uint8_t* frames, int64_t n, int h, int w, int channels, uint8_t* out_hashes,
+                             int32_t* out_quality) {
+    const int W = g_nctx;
+    if (W <= 1 || n < 4 * (int64_t)W || !frames || !out_hashes || !out_quality || h < 64 || w < 64)
+        return hash_frames_host(frames, n, h, w, channels, out_hashes, out_quality);
+    const size_t frame_bytes = (size_t)h * w * channels;
+    return run_on_group([&](int r) -> int {
+        const int64_t per = (n + W - 1) / W, lo = std::min<int64_t>(n, per * r), hi = std::min<int64_t>(n, lo + per);
+        return hash_frames_host(frames + frame_bytes * (size_t)lo, hi - lo, h, w, channels, out_hashes + 32 * lo, out_quality + lo);
+    });
+}
+
 int hvd_pdq_hash_frames_gray_u8(const uint8_t* frames, int64_t n, int h, int w, uint8_t* out_hashes,
                                 int32_t* out_quality) {
-    return hash_frames_host(frames, n, h, w, 1, out_hashes, out_quality);
+    return hash_frames_group(frames, n, h, w, 1, out_hashes, out_quality);
 }
 
 int hvd_pdq_hash_frames_rgb24_u8(const uint8_t* frames, int64_t n, int h, int w, uint8_t* out_hashes,
                                  int32_t* out_quality) {
-    return hash_frames_host(frames, n, h, w, 3, out_hashes, out_quality);
+    return hash_frames_group(frames, n, h, w, 3, out_hashes, out_quality);
 }
 
-// Runs the default all-pairs kernel (FP4-MFMA form) on a host DB; fetches up to `cap`
-// unordered records. Device buffers come from the grow-only pool (caller holds h_mu).
+// Runs the default all-pairs kernel (FP4-MFMA form) on a host DB -- this context's share of the tiles (rank of world) --
+// and fetches up to `cap` unordered records: its own when world == 1, every rank's after the group's exchange otherwise
+// (RCCL all-gather of counts then padded records between the devices, or host memory where the group has no RCCL).
+// *out_count = the true number of records over all ranks. Device buffers come from the grow-only pool (caller holds h_mu).
 static int allpairs_host_raw(const uint8_t* db, int64_t n, const int32_t* group, int max_dist,
-                             std::vector<hvd_pair>& recs, int64_t cap, int64_t* out_count) {
-    void *d_db = nullptr, *d_img = nullptr, *d_grp = nullptr, *d_pairs = nullptr;
-    unsigned long long* d_cnt = nullptr;
-    SCR(S_DB, 32 * (size_t)n, d_db);
-    HIP_TRY(hipMemcpyAsync(d_db, db, 32 * (size_t)n, hipMemcpyHostToDevice, g.stream));
-    size_t img_bytes = 0;
-    if (int rc = hvd_fp4_image_bytes(n, &img_bytes)) return rc;
-    SCR(S_IMG, img_bytes, d_img);
-    if (int rc = hvd_dev_expand_fp4(d_db, n, d_img)) return rc;
-    if (group) {
-        SCR(S_GRP, 4 * (size_t)n, d_grp);
-        HIP_TRY(hipMemcpyAsync(d_grp, group, 4 * (size_t)n, hipMemcpyHostToDevice, g.stream));
-    }
-    SCR(S_PAIRS, sizeof(hvd_pair) * (size_t)cap, d_pairs);
-    SCR(S_COUNTERS, 64, d_cnt);
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, g.stream));
-    if (int rc = hvd_dev_allpairs_hamming256_mfma(d_db, d_img, n, group ? d_grp : nullptr, max_dist, 0, 1, d_pairs, cap,
-                                                  d_cnt, HVD_DEFAULT_VARIANT))
-        return rc;
+                             std::vector<hvd_pair>& recs, int64_t cap, int64_t* out_count, int rank = 0, int world = 1) {
+    void* d_pairs = nullptr;
     unsigned long long cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_TRY(hipStreamSynchronize(g.stream));
-    *out_count = (int64_t)cnt;
-    const size_t m = (size_t)std::min<unsigned long long>(cnt, (unsigned long long)cap);
-    recs.resize(m);
-    if (m) {
-        HIP_TRY(hipMemcpyAsync(recs.data(), d_pairs, sizeof(hvd_pair) * m, hipMemcpyDeviceToHost, g.stream));
+    // Everything up to the exchange runs inside `local`: at world > 1 its result code rides along with the count, so that a
+    // rank that fails on its own does not leave the others waiting in the exchange (as in the video search, vmatch_build).
+    auto local = [&]() -> int {
+        void *d_db = nullptr, *d_img = nullptr, *d_grp = nullptr;
+        unsigned long long* d_cnt = nullptr;
+        SCR(S_DB, 32 * (size_t)n, d_db);
+        HIP_TRY(hipMemcpyAsync(d_db, db, 32 * (size_t)n, hipMemcpyHostToDevice, g.stream));
+        size_t img_bytes = 0;
+        if (int rc = hvd_fp4_image_bytes(n, &img_bytes)) return rc;
+        SCR(S_IMG, img_bytes, d_img);
+        if (int rc = hvd_dev_expand_fp4(d_db, n, d_img)) return rc;
+        if (group) {
+            SCR(S_GRP, 4 * (size_t)n, d_grp);
+            HIP_TRY(hipMemcpyAsync(d_grp, group, 4 * (size_t)n, hipMemcpyHostToDevice, g.stream));
+        }
+        SCR(S_PAIRS, sizeof(hvd_pair) * (size_t)cap, d_pairs);
+        SCR(S_COUNTERS, 64, d_cnt);
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 8, g.stream));
+        if (int rc = hvd_dev_allpairs_hamming256_mfma(d_db, d_img, n, group ? d_grp : nullptr, max_dist, rank, world, d_pairs,
+                                                      cap, d_cnt, HVD_DEFAULT_VARIANT))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(&cnt, d_cnt, 8, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
+        return HVD_OK;
+    };
+    const int local_rc = local();
+    const size_t mine = (size_t)std::min<unsigned long long>(cnt, (unsigned long long)cap);
+    if (world == 1) {
+        if (local_rc) return local_rc;
+        *out_count = (int64_t)cnt;
+        recs.resize(mine);
+        if (mine) {
+            HIP_TRY(hipMemcpyAsync(recs.data(), d_pairs, sizeof(hvd_pair) * mine, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+        }
+        return HVD_OK;
     }
+    // the true counts first (a rank whose own buffer overflowed must not truncate the total), then the records
+    const unsigned long long word[2] = {local_rc ? 0ull : cnt, local_rc ? 1ull : 0ull};
+    std::vector<unsigned long long> all;
+    if (int rc = exchange_words(word, all)) return local_rc ? local_rc : rc;
+    unsigned long long total = 0;
+    for (int r = 0; r < world; ++r) {
+        if (all[2 * (size_t)r + 1]) return local_rc ? local_rc : fail(HVD_ERR_RCCL, "all-pairs search abandoned: rank %d failed", r);
+        total += all[2 * (size_t)r];
+    }
+    *out_count = (int64_t)total;
+    if (total > (unsigned long long)cap) {  // every rank sees the same total: all of them skip the record exchange
+        recs.clear();
+        return HVD_OK;
+    }
+    recs.resize((size_t)total);
+    int64_t got = 0;
+    if (int rc = hvd_comm_allgather_pairs(d_pairs, (int64_t)mine, recs.data(), (int64_t)total, &got)) return rc;
+    if (got != (int64_t)total) return fail(HVD_ERR_RCCL, "candidate exchange returned %lld records, expected %llu", (long long)got, total);
     return HVD_OK;
 }
 
@@ -705,9 +999,28 @@ int hvd_allpairs_hamming256(const uint8_t* db, int64_t n, const int32_t* group, 
     *out_count = 0;
     if (n < 2) return HVD_OK;
     if (!db) return fail(HVD_ERR_ARG, "db is NULL");
-    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
     std::vector<hvd_pair> recs;
-    if (int rc = allpairs_host_raw(db, n, group, max_dist, recs, cap, out_count)) return rc;
+    const int W = (g_nctx > 1 && max_dist < 128 && n >= 4096) ? g_nctx : 1;  // small DBs: one device (launch-bound anyway)
+    int64_t total = 0;
+    if (W == 1) {
+        std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+        if (int rc = allpairs_host_raw(db, n, group, max_dist, recs, cap, &total)) return rc;
+    } else {
+        // DB replicated on every device of the group, tile (rb, cb) -> context (rb + cb) % W, candidates exchanged
+        int rc = run_on_group([&](int r) -> int {
+            std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+            std::vector<hvd_pair> mine;
+            int64_t t = 0;
+            if (int rc_ = allpairs_host_raw(db, n, group, max_dist, mine, cap, &t, r, W)) return rc_;
+            if (r == 0) {
+                recs.swap(mine);
+                total = t;
+            }
+            return HVD_OK;
+        });
+        if (rc) return rc;
+    }
+    *out_count = total;
     if (*out_count > cap)
         return fail(HVD_ERR_OVERFLOW, "pair buffer too small: need %lld records, cap %lld", (long long)*out_count,
                     (long long)cap);
@@ -836,6 +1149,7 @@ struct VmArgs {
     const int32_t *d_excl_q, *d_excl_t;  // rect only: frames with equal values are not compared (nullable)
     int max_dist;                        // [0,127]
     int rank, world;
+    int pre_rc = 0;                      // a failure of this rank BEFORE the search (upload): reported through the agreement step
 };
 
 int read_counters(unsigned long long* d_counters, unsigned long long out[4]) {
@@ -849,7 +1163,7 @@ int read_counters(unsigned long long* d_counters, unsigned long long out[4]) {
 // step that overflowed is repeated; the inputs never move.
 int vmatch_build(const VmArgs& v) {
     const bool exchange = g.v_exchange_mode == 1 || (g.v_exchange_mode == 0 && v.world > 1);
-    if (exchange && (!g.comm_ready || g.world != v.world || g.rank != v.rank))
+    if (exchange && ((!g.comm_ready && !g.host_exchange) || g.world != v.world || g.rank != v.rank))
         return fail(HVD_ERR_STATE, "rank %d of %d needs hvd_comm_init() with the same rank/world first", v.rank, v.world);
     // world > 1: a rank that fails on its own (out of memory while a table regrows, a launch error) must not leave its
     // peers blocked in the all-gathers below. Everything up to the exchange runs inside `local`, whose result code rides
@@ -859,6 +1173,7 @@ int vmatch_build(const VmArgs& v) {
     unsigned long long* d_set = nullptr;
     unsigned long long c[4] = {0, 0, 0, 0};
     auto local = [&]() -> int {
+    if (v.pre_rc) return v.pre_rc;
     SCR(S_COUNTERS, 64, d_counters);
     // the pair-queue form of the all-pairs kernel settles its candidates on PACKED hashes; this entry is handed images only
     void *d_bits_t = nullptr, *d_bits_q = nullptr;
@@ -889,6 +1204,7 @@ int vmatch_build(const VmArgs& v) {
         a.d_count = d_counters + 3;
         a.variant = HVD_DEFAULT_VARIANT;
         a.col_chunk = 0;
+    a.ctx_id = t_ctx;
         a.sink = hvd::VideoSink{d_set, slots - 1, d_counters, v.d_vid_q, v.d_vid_t};
         hipError_t e = v.rect ? hvd::launch_cross_mfma(a, v.d_img_q, v.nq, v.d_img_t, v.d_excl_t, g.stream)
                               : hvd::launch_allpairs_mfma(a, v.d_img_t, g.stream);
@@ -907,14 +1223,24 @@ int vmatch_build(const VmArgs& v) {
         // each rank saw only its tiles' hits: all-gather the key lists and de-duplicate (a key may be found twice)
         unsigned long long *d_list = nullptr, *d_all = nullptr, *d_set2 = nullptr;
         const int W = g.world;
-        // (the two small exchange words were allocated by hvd_comm_init: nothing can fail between here and the collective)
+        // (the two small exchange words were allocated with the communicator: nothing can fail between here and the collective)
         unsigned long long word[2] = {local_rc ? 0ull : n_keys, (unsigned long long)(unsigned)(local_rc ? 1 : 0)};
         std::vector<unsigned long long> words(2 * (size_t)W);
         auto agree = [&](const char* what, int own_rc) -> int {  // all-gather (count, status); a failure anywhere -> everyone leaves
-            HIP_TRY(hipMemcpyAsync(g.x_cnt_in, word, 16, hipMemcpyHostToDevice, g.stream));
-            NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 2, ncclUint64, g.comm, g.stream));
-            HIP_TRY(hipMemcpyAsync(words.data(), g.x_cnt_all, 16 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
-            HIP_TRY(hipStreamSynchronize(g.stream));
+            if (g.host_exchange) {  // group without RCCL: the words meet in host memory
+                g_hx.barrier(W);    // (everybody is done with the previous round's slots)
+                g_hx.words[(size_t)g.rank].assign(word, word + 2);
+                g_hx.barrier(W);
+                for (int r = 0; r < W; ++r) {
+                    words[2 * (size_t)r] = g_hx.words[(size_t)r][0];
+                    words[2 * (size_t)r + 1] = g_hx.words[(size_t)r][1];
+                }
+            } else {
+                HIP_TRY(hipMemcpyAsync(g.x_cnt_in, word, 16, hipMemcpyHostToDevice, g.stream));
+                NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 2, ncclUint64, g.comm, g.stream));
+                HIP_TRY(hipMemcpyAsync(words.data(), g.x_cnt_all, 16 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+            }
             for (int r = 0; r < W; ++r)
                 if (words[2 * (size_t)r + 1]) {
                     if (own_rc) return own_rc;  // our own failure: its message is already recorded
@@ -940,7 +1266,20 @@ int vmatch_build(const VmArgs& v) {
         HIP_TRY(hipMemsetAsync(d_list, 0xFF, 8 * mx, g.stream));
         HIP_TRY(hipMemsetAsync(d_counters + 2, 0, 8, g.stream));
         HIP_TRY(hvd::launch_set_to_list(d_set, slots, d_list, mx, d_counters + 2, g.stream));
-        NCCL_TRY(ncclAllGather(d_list, d_all, 8 * mx, ncclUint8, g.comm, g.stream));
+        if (g.host_exchange) {  // every rank's list through host memory, the concatenation back to every device
+            std::vector<unsigned long long>& mine = g_hx.words[(size_t)g.rank];
+            g_hx.barrier(W);
+            mine.resize((size_t)mx);
+            HIP_TRY(hipMemcpyAsync(mine.data(), d_list, 8 * (size_t)mx, hipMemcpyDeviceToHost, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            g_hx.barrier(W);
+            for (int r = 0; r < W; ++r)
+                HIP_TRY(hipMemcpyAsync(d_all + (size_t)r * mx, g_hx.words[(size_t)r].data(), 8 * (size_t)mx, hipMemcpyHostToDevice, g.stream));
+            HIP_TRY(hipStreamSynchronize(g.stream));
+            g_hx.barrier(W);  // (the slots are free again only when everybody has copied them)
+        } else {
+            NCCL_TRY(ncclAllGather(d_list, d_all, 8 * mx, ncclUint8, g.comm, g.stream));
+        }
         unsigned long long slots2 = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * total));
         if (g.v_force_slots_log2) slots2 = 1ull << g.v_force_slots_log2;
         for (;;) {
@@ -1057,8 +1396,33 @@ int hvd_vpdq_match_videos(const uint8_t* frames, const int64_t* offsets, int64_t
     if (int rc = check_offsets(offsets, V, &nf)) return rc;
     if (nf < 2) return HVD_OK;
     if (!frames) return fail(HVD_ERR_ARG, "frames is NULL");
-    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
     std::vector<hvd_vmatch> res;
+    if (g_nctx > 1 && max_dist < 128 && nf >= 4096) {
+        // the group: library replicated on every device, tile (rb, cb) -> context (rb + cb) % W, key sets exchanged inside
+        // vmatch_build (RCCL all-gather between the devices, host memory where the group has no RCCL); every rank ends up
+        // with the whole result, rank 0's is returned
+        const int W = g_nctx;
+        int rc = run_on_group([&](int r) -> int {
+            std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+            void* d_img = nullptr;
+            int32_t* d_vid = nullptr;
+            const int up = upload_library(frames, offsets, V, nf, Ctx::S_DB, Ctx::S_IMG, Ctx::S_VIDQ, &d_img, &d_vid);
+            VmArgs v{d_img, (uint32_t)nf, d_img, (uint32_t)nf, false, d_vid, d_vid, nullptr, nullptr, max_dist, r, W};
+            v.pre_rc = up;
+            std::vector<hvd_vmatch> mine;
+            if (int rc_ = vmatch_to_host(v, V, mine)) return rc_;
+            if (r == 0) res.swap(mine);
+            return HVD_OK;
+        });
+        if (rc) return rc;
+        *out_count = (int64_t)res.size();
+        if ((int64_t)res.size() > cap)
+            return fail(HVD_ERR_OVERFLOW, "video match buffer too small: need %lld, cap %lld", (long long)res.size(),
+                        (long long)cap);
+        if (!res.empty()) memcpy(out, res.data(), sizeof(hvd_vmatch) * res.size());
+        return HVD_OK;
+    }
+    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
     if (max_dist >= 128) {
         // popcount route (a tolerance the reference never uses): frame-level hits reduced on the host
         std::vector<int32_t> vid((size_t)nf);
@@ -1100,26 +1464,51 @@ int hvd_vpdq_match_videos_cross(const uint8_t* frames_q, const int64_t* offsets_
     if (int rc = check_offsets(offsets_t, VT, &nt)) return rc;
     if (nq == 0 || nt == 0) return HVD_OK;
     if (!frames_q || !frames_t) return fail(HVD_ERR_ARG, "frames is NULL");
-    std::lock_guard<std::recursive_mutex> lk(g.h_mu);
-    void *d_iq = nullptr, *d_it = nullptr;
-    int32_t *d_vq = nullptr, *d_vt = nullptr, *d_gq = nullptr, *d_gt = nullptr;
-    if (int rc = upload_library(frames_q, offsets_q, VQ, nq, Ctx::S_DB, Ctx::S_IMG, Ctx::S_VIDQ, &d_iq, &d_vq)) return rc;
-    if (int rc = upload_library(frames_t, offsets_t, VT, nt, Ctx::S_DB2, Ctx::S_IMG2, Ctx::S_VIDT, &d_it, &d_vt)) return rc;
+    std::vector<int32_t> gq, gt;
     if (ids_q) {  // frames of videos with equal ids are not compared (a query that is also in the target set)
-        std::vector<int32_t> gq((size_t)nq), gt((size_t)nt);
+        gq.resize((size_t)nq);
+        gt.resize((size_t)nt);
         for (int64_t v = 0; v < VQ; ++v)
             for (int64_t f = offsets_q[v]; f < offsets_q[v + 1]; ++f) gq[(size_t)f] = ids_q[v];
         for (int64_t v = 0; v < VT; ++v)
             for (int64_t f = offsets_t[v]; f < offsets_t[v + 1]; ++f) gt[(size_t)f] = ids_t[v];
-        SCR(S_GRP, 4 * (size_t)nq, d_gq);
-        SCR(S_GRP2, 4 * (size_t)nt, d_gt);
-        HIP_TRY(hipMemcpyAsync(d_gq, gq.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipMemcpyAsync(d_gt, gt.data(), 4 * (size_t)nt, hipMemcpyHostToDevice, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));  // gq/gt are stack-scoped
     }
-    VmArgs v{d_iq, (uint32_t)nq, d_it, (uint32_t)nt, true, d_vq, d_vt, d_gq, d_gt, max_dist, 0, 1};
+    // one rank's share (rank r of W contexts; W = 1: the whole rectangle on the current context)
+    auto one = [&](int r, int W, std::vector<hvd_vmatch>& res) -> int {
+        std::lock_guard<std::recursive_mutex> lk(g.h_mu);
+        void *d_iq = nullptr, *d_it = nullptr;
+        int32_t *d_vq = nullptr, *d_vt = nullptr, *d_gq = nullptr, *d_gt = nullptr;
+        auto upload = [&]() -> int {
+            if (int rc = upload_library(frames_q, offsets_q, VQ, nq, Ctx::S_DB, Ctx::S_IMG, Ctx::S_VIDQ, &d_iq, &d_vq)) return rc;
+            if (int rc = upload_library(frames_t, offsets_t, VT, nt, Ctx::S_DB2, Ctx::S_IMG2, Ctx::S_VIDT, &d_it, &d_vt)) return rc;
+            if (ids_q) {
+                SCR(S_GRP, 4 * (size_t)nq, d_gq);
+                SCR(S_GRP2, 4 * (size_t)nt, d_gt);
+                HIP_TRY(hipMemcpyAsync(d_gq, gq.data(), 4 * (size_t)nq, hipMemcpyHostToDevice, g.stream));
+                HIP_TRY(hipMemcpyAsync(d_gt, gt.data(), 4 * (size_t)nt, hipMemcpyHostToDevice, g.stream));
+                HIP_TRY(hipStreamSynchronize(g.stream));
+            }
+            return HVD_OK;
+        };
+        const int up = upload();
+        if (W == 1 && up) return up;
+        VmArgs v{d_iq, (uint32_t)nq, d_it, (uint32_t)nt, true, d_vq, d_vt, d_gq, d_gt, max_dist, r, W};
+        v.pre_rc = up;
+        return vmatch_to_host(v, VQ, res);
+    };
     std::vector<hvd_vmatch> res;
-    if (int rc = vmatch_to_host(v, VQ, res)) return rc;
+    if (g_nctx > 1 && nq + nt >= 4096) {
+        const int W = g_nctx;
+        int rc = run_on_group([&](int r) -> int {
+            std::vector<hvd_vmatch> mine;
+            if (int rc_ = one(r, W, mine)) return rc_;
+            if (r == 0) res.swap(mine);
+            return HVD_OK;
+        });
+        if (rc) return rc;
+    } else if (int rc = one(0, 1, res)) {
+        return rc;
+    }
     *out_count = (int64_t)res.size();
     if ((int64_t)res.size() > cap)
         return fail(HVD_ERR_OVERFLOW, "video match buffer too small: need %lld, cap %lld", (long long)res.size(),
@@ -1304,6 +1693,21 @@ int hvd_comm_abort(void) {
 
 int hvd_comm_allgather_bytes(const void* d_send, void* d_recv, size_t bytes_per_rank) {
     if (int rc = need_ready()) return rc;
+    if (g.host_exchange) {  // in-process group without RCCL: through host memory (every context's thread calls this)
+        const int W = g.world;
+        std::vector<unsigned long long>& mine = g_hx.words[(size_t)g.rank];
+        g_hx.barrier(W);
+        mine.resize((bytes_per_rank + 7) / 8);
+        if (bytes_per_rank) HIP_TRY(hipMemcpyAsync(mine.data(), d_send, bytes_per_rank, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        g_hx.barrier(W);
+        for (int r = 0; r < W && bytes_per_rank; ++r)
+            HIP_TRY(hipMemcpyAsync((char*)d_recv + (size_t)r * bytes_per_rank, g_hx.words[(size_t)r].data(), bytes_per_rank,
+                                   hipMemcpyHostToDevice, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        g_hx.barrier(W);
+        return HVD_OK;
+    }
     if (!g.comm_ready) return fail(HVD_ERR_STATE, "hvd_comm_init() has not been called");
     NCCL_TRY(ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, g.comm, g.stream));
     return HVD_OK;
@@ -1323,8 +1727,33 @@ static int grow(void** p, size_t* cap, size_t need) {
 int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_host, int64_t cap,
                              int64_t* out_total) {
     if (int rc = need_ready()) return rc;
-    if (!g.comm_ready) return fail(HVD_ERR_STATE, "hvd_comm_init() has not been called");
     if (count < 0 || cap < 0 || !out_total) return fail(HVD_ERR_ARG, "bad arguments");
+    if (g.host_exchange) {  // in-process group without RCCL: the ranks' records meet in host memory
+        const int W = g.world;
+        std::vector<unsigned long long>& mine = g_hx.words[(size_t)g.rank];
+        g_hx.barrier(W);
+        mine.resize(2 * (size_t)count);
+        if (count) HIP_TRY(hipMemcpyAsync(mine.data(), d_pairs, sizeof(hvd_pair) * (size_t)count, hipMemcpyDeviceToHost, g.stream));
+        HIP_TRY(hipStreamSynchronize(g.stream));
+        g_hx.barrier(W);
+        size_t total = 0;
+        for (int r = 0; r < W; ++r) total += g_hx.words[(size_t)r].size() / 2;
+        *out_total = (int64_t)total;
+        int rc = HVD_OK;
+        if ((int64_t)total > cap) rc = fail(HVD_ERR_OVERFLOW, "need %zu records, cap %lld", total, (long long)cap);
+        else if (total && !out_host) rc = fail(HVD_ERR_ARG, "out_host is NULL");
+        else {
+            size_t o = 0;
+            for (int r = 0; r < W; ++r) {
+                const size_t m = g_hx.words[(size_t)r].size() / 2;
+                if (m) memcpy(out_host + o, g_hx.words[(size_t)r].data(), sizeof(hvd_pair) * m);
+                o += m;
+            }
+        }
+        g_hx.barrier(W);
+        return rc;
+    }
+    if (!g.comm_ready) return fail(HVD_ERR_STATE, "hvd_comm_init() has not been called");
     const int W = g.world;
     // 1) counts
     if (!g.x_cnt_in || !g.x_cnt_all) return fail(HVD_ERR_STATE, "exchange words missing: hvd_comm_init() allocates them");

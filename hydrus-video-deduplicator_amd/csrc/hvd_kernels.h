@@ -21,6 +21,7 @@ struct AllPairsArgs {
     unsigned long long* d_count;
     int variant;
     uint32_t col_chunk;      // 0 = pick automatically
+    int ctx_id = 0;          // the caller's context: selects the FP4-MFMA forms' per-context select/context words
     VideoSink sink = {nullptr, 0, nullptr, nullptr, nullptr};  // FP4-MFMA form only: reduce to video level (K3)
 };
 
@@ -39,7 +40,7 @@ hipError_t launch_allpairs_mfma(const AllPairsArgs& a, const void* d_img, hipStr
 // for queries and d_group_t for targets; pass both or neither).
 hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
                              const int32_t* d_group_t, hipStream_t s);
-hipError_t mfma_select_buffer(uint32_t** out);  // [0] = form the auto variant ran last, [1] = probe survivors
+hipError_t mfma_select_buffer(int ctx_id, uint32_t** out);  // per context; [0] = form the auto variant ran last, [1] = probe survivors
 void mfma_release();
 void pdq_release();           // k_pdq.hip: free the hash kernel's work-counter ring (hvd_shutdown)
 void stream_release_cache();  // hvd_stream.cpp: free the parked hasher slot sets (hvd_shutdown)

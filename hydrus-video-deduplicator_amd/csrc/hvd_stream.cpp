@@ -21,6 +21,8 @@ namespace hvd {
 int api_fail(int code, const char* fmt, ...);     // hvd_api.cpp
 const float* api_dct_device();                    // hvd_api.cpp; nullptr before hvd_init
 int api_bind_device();                            // hvd_api.cpp: hipSetDevice(bound device) for the calling thread
+int api_context();                                // the calling thread's current context of the device group
+void api_set_context(int idx);
 size_t api_scratch_bytes(int64_t n, int h, int w, int channels);
 hipError_t api_launch_hash(const void* d_frames, int64_t n, int h, int w, int channels, void* d_scratch, void* d_hashes,
                            void* d_quality, hipStream_t s);
@@ -178,6 +180,7 @@ extern "C" int hvd_debug_parallel_copy(void* dst, const void* src, size_t n, int
 #endif
 
 struct hvd_hasher {
+    int ctx = 0;           // the context (device of the group) this hasher was created on: every call runs there
     int copy_threads = 4;  // threads that share one frame's copy into the ring (hvd_hasher_set_threads)
     int w = 0, h = 0, channels = 0;
     int64_t batch = 0;
@@ -188,6 +191,18 @@ struct hvd_hasher {
     std::vector<int32_t> quality;
     bool acquired = false;         // hvd_hasher_acquire handed out the next frame's slot memory
 };
+
+// A hasher lives on the context it was created on, whatever context the calling thread has selected.
+namespace {
+struct CtxScope {
+    int saved;
+    explicit CtxScope(int ctx) : saved(hvd::api_context()) { hvd::api_set_context(ctx); }
+    ~CtxScope() {
+        hvd::api_set_context(saved);
+        (void)hvd::api_bind_device();
+    }
+};
+}  // namespace
 
 #define S_TRY(expr)                                                                                        \
     do {                                                                                                   \
@@ -257,6 +272,7 @@ extern "C" {
 
 int hvd_hasher_destroy(hvd_hasher* hs) {
     if (!hs) return HVD_OK;
+    CtxScope scope(hs->ctx);
     (void)hvd::api_bind_device();
     bool complete = true;
     for (Slot& s : hs->slot) {
@@ -293,7 +309,7 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
         std::lock_guard<std::mutex> lk(g_park_mu);
         for (size_t k = g_parked.size(); k-- > 0;) {
             hvd_hasher* p = g_parked[k];
-            if (p->w == width && p->h == height && p->channels == channels && p->batch == batch_frames) {
+            if (p->ctx == hvd::api_context() && p->w == width && p->h == height && p->channels == channels && p->batch == batch_frames) {
                 g_parked.erase(g_parked.begin() + (long)k);
                 p->copy_threads = 4;
                 *out = p;
@@ -301,7 +317,9 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
             }
         }
     }
+    if (int rc = hvd::api_bind_device()) return rc;
     hvd_hasher* hs = new hvd_hasher();
+    hs->ctx = hvd::api_context();
     hs->w = width;
     hs->h = height;
     hs->channels = channels;
@@ -335,6 +353,7 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
  * hashed. The frame counts once hvd_hasher_commit() is called; acquire without commit may be repeated. */
 int hvd_hasher_acquire(hvd_hasher* hs, uint8_t** out_frame) {
     if (!hs || !out_frame) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/out_frame");
+    CtxScope scope(hs->ctx);
     if (int rc = hvd::api_bind_device()) return rc;
     Slot& s = hs->slot[hs->cur];
     if (s.filled == 0 && s.in_flight) {  // slot being reused: its previous batch must have landed
@@ -347,6 +366,7 @@ int hvd_hasher_acquire(hvd_hasher* hs, uint8_t** out_frame) {
 
 int hvd_hasher_commit(hvd_hasher* hs) {
     if (!hs) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher");
+    CtxScope scope(hs->ctx);
     if (!hs->acquired) return hvd::api_fail(HVD_ERR_STATE, "hvd_hasher_commit() without hvd_hasher_acquire()");
     if (int rc = hvd::api_bind_device()) return rc;
     hs->acquired = false;
@@ -381,6 +401,7 @@ int hvd_hasher_set_threads(hvd_hasher* hs, int n) {
  * is empty afterwards and can be reused for the next video. */
 int hvd_hasher_finish(hvd_hasher* hs, uint8_t* out_hashes, int32_t* out_quality, int64_t cap, int64_t* out_n) {
     if (!hs || !out_n) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/out_n");
+    CtxScope scope(hs->ctx);
     if (int rc = hvd::api_bind_device()) return rc;
     hs->acquired = false;
     // Slots are submitted in ring order, so the oldest batch still in flight sits in the slot that will be

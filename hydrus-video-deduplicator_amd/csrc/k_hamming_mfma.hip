@@ -1055,7 +1055,7 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
     if (c.db_q == nullptr || c.db_t == nullptr || !g_mfma_queue_packed) c.db_q = c.db_t = nullptr;
     c.max_dist = a.max_dist;
     uint32_t* sel = nullptr;
-    c.qstats = mfma_select_buffer(&sel) == hipSuccess ? reinterpret_cast<unsigned long long*>(sel + 128) : nullptr;
+    c.qstats = mfma_select_buffer(a.ctx_id, &sel) == hipSuccess ? reinterpret_cast<unsigned long long*>(sel + 128) : nullptr;
     return c;
 }
 
@@ -1080,7 +1080,7 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
     }
     dim3 grid((unsigned)n_rb, (unsigned)((n_pad + chunk - 1) / chunk));
     uint32_t* buf = nullptr;
-    hipError_t e = mfma_select_buffer(&buf);
+    hipError_t e = mfma_select_buffer(a.ctx_id, &buf);
     if (e != hipSuccess) return e;
     HitCtx* ctx = reinterpret_cast<HitCtx*>(buf + 16);
     hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1, rect ? d_img_q : d_img, d_img));
@@ -1110,35 +1110,42 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
 }
 
 // select[0] = form to run, select[1] / select[2] = first-stage survivors the probe counted over bits 0..127 / 128..255,
-// select[3] = 1: the first stage runs on bits 128..255. One per process (all
-// launches go to the one library stream).
-static uint32_t* g_select = nullptr;
-// The hit context and the select words are shared device state written in stream order right before the kernels that
+// select[3] = 1: the first stage runs on bits 128..255. One buffer per CONTEXT of the library (a context = one stream on one
+// device; a group may hold two contexts on one device, whose passes run concurrently on their own streams).
+constexpr int kMaxSelect = 16;
+static uint32_t* g_select[kMaxSelect] = {};
+// The hit context and the select words are device state written in stream order right before the kernels that
 // read them: two host threads enqueueing passes at once must not interleave "write context, launch" sequences.
 static std::mutex g_launch_mu;
 
-hipError_t mfma_select_buffer(uint32_t** out) {
-    if (!g_select) {
+hipError_t mfma_select_buffer(int ctx_id, uint32_t** out) {
+    if (ctx_id < 0 || ctx_id >= kMaxSelect) return hipErrorInvalidValue;
+    static std::mutex alloc_mu;
+    std::lock_guard<std::mutex> lk(alloc_mu);
+    if (!g_select[ctx_id]) {
         static_assert(sizeof(HitCtx) <= 192, "hit context does not fit its slot");
         // 16 B of select words, the hit context at +64, 16 counters of HVD_K2_QSTATS builds at +512
-        hipError_t e = hipMalloc((void**)&g_select, 1024);
+        uint32_t* p = nullptr;
+        hipError_t e = hipMalloc((void**)&p, 1024);
         // (hipMemset on device memory does not wait: without the synchronisation it can land on top of the first context
         // that the non-blocking library stream writes)
-        if (e == hipSuccess) e = hipMemset(g_select, 0, 1024);
+        if (e == hipSuccess) e = hipMemset(p, 0, 1024);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) {
-            if (g_select) (void)hipFree(g_select);
-            g_select = nullptr;
+            if (p) (void)hipFree(p);
             return e;
         }
+        g_select[ctx_id] = p;
     }
-    *out = g_select;
+    *out = g_select[ctx_id];
     return hipSuccess;
 }
 
 void mfma_release() {
-    if (g_select) (void)hipFree(g_select);
-    g_select = nullptr;
+    for (uint32_t*& p : g_select) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
 }
 
 // Probe, decide on the device, launch both candidate forms: the one the probe did not choose returns at once.
@@ -1147,7 +1154,7 @@ void mfma_release() {
 static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q, uint32_t nq,
                               const int32_t* d_group_t, hipStream_t s) {
     uint32_t* sel = nullptr;
-    hipError_t e = mfma_select_buffer(&sel);
+    hipError_t e = mfma_select_buffer(a.ctx_id, &sel);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(sel, 0, 16, s);
     if (e != hipSuccess) return e;

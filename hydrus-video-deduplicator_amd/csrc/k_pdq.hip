@@ -1423,27 +1423,34 @@ bool pdq_dct_table_matches(const float* host_16x64) {
 // self-cleaning alone -- the launch's last draw zeroes its slot -- left a non-zero slot behind a faulted or aborted launch,
 // and the launch handed that slot 256 launches later skipped chunks silently; the one-off clearing also ran on the null
 // stream, unordered with the non-blocking streams the kernels run on). ~2 us per launch of >= 64 k frames.
-static std::atomic<unsigned int*> g_hash_work{nullptr};
+constexpr int kMaxWorkDevices = 16;  // one ring per HIP device (contexts that share a device share its ring: a slot is per launch)
+static std::atomic<unsigned int*> g_hash_work[kMaxWorkDevices] = {};
 static std::atomic<unsigned int> g_hash_work_next{0};
 constexpr unsigned int kHashWorkSlots = 256;
 
 void pdq_release() {
-    unsigned int* p = g_hash_work.exchange(nullptr);
-    if (p) (void)hipFree(p);
+    for (auto& w : g_hash_work) {
+        unsigned int* p = w.exchange(nullptr);
+        if (p) (void)hipFree(p);
+    }
 }
 
-// the next counter slot of the ring (allocated on first use), zeroed in stream order
+// the next counter slot of the current device's ring (allocated on first use), zeroed in stream order
 static hipError_t work_slot(unsigned int** out, hipStream_t s) {
-    unsigned int* base = g_hash_work.load(std::memory_order_acquire);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxWorkDevices) return hipErrorInvalidDevice;
+    unsigned int* base = g_hash_work[dev].load(std::memory_order_acquire);
     if (!base) {
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
-        base = g_hash_work.load(std::memory_order_acquire);
+        base = g_hash_work[dev].load(std::memory_order_acquire);
         if (!base) {
             unsigned int* p = nullptr;
-            hipError_t e = hipMalloc((void**)&p, kHashWorkSlots * 2 * sizeof(unsigned int));
+            e = hipMalloc((void**)&p, kHashWorkSlots * 2 * sizeof(unsigned int));
             if (e != hipSuccess) return e;
-            g_hash_work.store(p, std::memory_order_release);
+            g_hash_work[dev].store(p, std::memory_order_release);
             base = p;
         }
     }

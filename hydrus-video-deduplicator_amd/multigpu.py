@@ -102,6 +102,53 @@ class RcclExchange:
         _lib.check(_lib.load().hvd_comm_abort())
 
 
+class GroupExchange(RcclExchange):
+    """The exchange of the IN-PROCESS device group (hvd_init_devices / HVD_DEVICES): one thread per context calls the same
+    entry points, which all-gather over the group's communicators (ncclCommInitAll) -- or through host memory where the
+    group lists a device twice. Nothing to set up and nothing to tear down: the communicators belong to the library."""
+
+    def __init__(self, rank: int, world: int):  # noqa: super().__init__ would create a communicator
+        self.rank, self.world = rank, world
+
+    def close(self) -> None:
+        pass
+
+    def abort(self) -> None:
+        pass
+
+
+def run_on_contexts(fn, world: int | None = None) -> list:
+    """fn(rank, world) on every context of the library's device group, one Python thread per context (ctypes releases the
+    GIL during the calls; each thread selects its context first). -> [fn's result per rank]; the first exception is
+    re-raised after every thread has finished."""
+    import threading
+
+    world = _lib.context_count() if world is None else world
+    if world <= 1:
+        _lib.set_context(0)
+        return [fn(0, 1)]
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            _lib.set_context(r)
+            out[r] = fn(r, world)
+        except BaseException as exc:  # noqa: BLE001 - re-raised below
+            err[r] = exc
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(1, world)]
+    for t in ts:
+        t.start()
+    body(0)
+    for t in ts:
+        t.join()
+    _lib.set_context(0)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
 class HostExchange:
     """The same all-gather of candidate pairs over the control channel (hvd_amd.rendezvous, plain TCP on the
     loopback interface): what the world_size-2 CPU tests run, and the degraded path of bench.py when the RCCL

@@ -260,6 +260,28 @@ def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, 
     return pairs, recs, None
 
 
+def dedupe_frames_in_process(frames_of_rank, raw_offsets: np.ndarray, h: int, w: int, channels: int,
+                             threshold: float = 50.0, policy: str | None = None, timings: dict | None = None):
+    """BASELINE config 5 on the library's in-process device group (hvd_init_devices / HVD_DEVICES), no launcher:
+    one thread per context runs `dedupe_frames_on_device` as rank = context index. frames_of_rank(rank, world) ->
+    device pointer of the frames of that rank's video range (`video_range_of_rank`), resident on that rank's device (it is
+    called on the rank's thread, with the rank's context current). -> (pairs, records) -- every rank computes the same;
+    rank 0's are returned. timings: rank 0's stage times."""
+    from . import multigpu
+
+    def one(rank, world):
+        ex = multigpu.GroupExchange(rank, world) if world > 1 else None
+        tm = {} if timings is not None and rank == 0 else None
+        pairs, recs, _ = dedupe_frames_on_device(frames_of_rank(rank, world), raw_offsets, h, w, channels, threshold, policy,
+                                                 rank, world, ex, timings=tm)
+        if tm is not None:
+            timings.update(tm)
+        return pairs, recs
+
+    results = multigpu.run_on_contexts(one)
+    return results[0]
+
+
 def video_range_of_rank(V: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous share of the videos hashed by `rank` (frames are independent: no collective while hashing)."""
     per = (V + world - 1) // world

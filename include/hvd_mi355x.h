@@ -39,7 +39,7 @@ extern "C" {
 
 #define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
 #define HVD_UNIQUE_ID_BYTES 128
-#define HVD_ABI_VERSION 3 /* 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
+#define HVD_ABI_VERSION 4 /* 4 (round 4): + hvd_init_devices, hvd_context_count, hvd_set_context, hvd_get_context, hvd_group_exchange; 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
 /* All-pairs kernel the host entry points use: FP4-MFMA with a 128-bit first stage; which of its two forms runs
  * (survivors fetch their other half | second stage out of registers) is chosen per launch from a probe of the data. */
 #define HVD_DEFAULT_VARIANT 13
@@ -57,9 +57,27 @@ typedef struct {
 int hvd_abi_version(void);
 /* Number of visible HIP devices (0 and HVD_OK when there is none). */
 int hvd_device_count(int* out_n);
-/* Bind this process to one GPU ("one process per GPU"), create the library stream,
- * upload the 16x64 DCT matrix. Idempotent for the same device. */
+/* Bind this process to one GPU, create the library stream, upload the 16x64 DCT matrix. Idempotent for the same
+ * device. With HVD_DEVICES=0,1,2,... in the environment (the list must start with `device`) this is
+ * hvd_init_devices() on that list: every binding of this library that calls hvd_init -- the vpdq-shaped Python
+ * surface, the search, the VpTreeManager facade, the SQLite adapter -- then uses all listed GPUs, no launcher. */
 int hvd_init(int device);
+/* Bind this process to a GROUP of GPUs: one context per listed device (its own stream, scratch pool, select/context
+ * words, communicator). The reference is ONE process (entrypoint.py:235 -> dedup.py:213); a group is how that one
+ * process uses 8 MI355X. The host-buffer entry points (hvd_pdq_hash_frames_*, hvd_allpairs_hamming256,
+ * hvd_vpdq_match_videos[_cross]) then shard by themselves -- frames in contiguous ranges; the hash DB replicated on
+ * every device, tile (rb, cb) of the pair matrix on context (rb + cb) % n, one host thread per context, candidates /
+ * video keys exchanged with RCCL all-gathers over xGMI (ncclCommInitAll: one communicator per device, one process) --
+ * and return what a single device returns. Everything else works on the calling thread's CURRENT context
+ * (hvd_set_context; context 0 by default): a caller that wants to drive the device-resident API on every GPU itself
+ * runs one thread per context with rank = context index, world = group size (hvd_amd.pipeline, bench.py
+ * --single-process). A device may be listed twice (two contexts, two streams on one GPU: a test configuration; RCCL
+ * refuses duplicate devices, so such a group exchanges through host memory -- hvd_group_exchange() == 2). */
+int hvd_init_devices(const int* devices, int n_devices);
+int hvd_context_count(int* out_n);  /* contexts of the group (1 after hvd_init, 0 before) */
+int hvd_set_context(int index);     /* the calling thread's current context (and HIP device) from now on */
+int hvd_get_context(void);
+int hvd_group_exchange(void);       /* 0: no group (one context); 1: RCCL between the devices; 2: host memory */
 int hvd_shutdown(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf. */
 int hvd_last_error(char* buf, size_t len);
