@@ -165,7 +165,7 @@ def test_videohasher_two_threads_with_different_copy_thread_counts(gpu, hvd, ora
 
     rgb = hvd.synth.frames_rgb(8, seed=52)
     want_h, want_q = oracle.hash_frames(rgb)
-    assert (want_q >= 31).all()
+    assert (want_q >= 31).sum() >= 4  # (finish() drops the others, vpdqpy/vpdqpy.py:119 / db/DedupeDB.py:550-553)
     errors = []
 
     def pusher(num_threads, videos, frames_per_video, phase):
@@ -176,7 +176,8 @@ def test_videohasher_two_threads_with_different_copy_thread_counts(gpu, hvd, ora
                 order = [(v * 3 + phase + k) % 8 for k in range(frames_per_video)]
                 for k in order:
                     h.hash_frame(blobs[k])
-                if h.finish().bytes != want_h[order].tobytes():
+                order = np.array(order)
+                if h.finish().bytes != want_h[order][want_q[order] >= 31].tobytes():
                     errors.append((num_threads, v))
                     return
         except Exception as exc:  # noqa: BLE001 - reported below
