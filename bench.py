@@ -83,6 +83,11 @@ def parse():
     ap.add_argument("--sustain-seconds", type=float, default=12.0, help="length of the sustained leg at N=1 (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline + frames_hashed only")
     ap.add_argument("--cfg5-videos", type=int, default=50_000)
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 inside ONE process: the library's device group (hvd_init_devices, ncclCommInitAll), one "
+                         "thread per GPU -- the mode the drop-in surfaces use (HVD_DEVICES); default: one process per GPU")
+    ap.add_argument("--devices", type=str, default="", help="--single-process: comma-separated device list (default 0..N-1; "
+                                                             "a device may be listed twice: host-memory exchange)")
     return ap.parse_args()
 
 
@@ -260,6 +265,8 @@ def self_launch(n: int) -> int:
 
 def main():
     args = parse()
+    if args.single_process and args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(single_process(args))
     if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
     # Native libraries (RCCL) print banners on fd 1; the contract is ONE JSON line on stdout.
@@ -272,7 +279,53 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world  # a launcher's WORLD_SIZE wins over the flag
+    rank_main(args, rank, local_rank, world, real_stdout, None)
 
+
+def single_process(args) -> int:
+    """`python bench.py --gpus N --single-process`: the N ranks are the N contexts of the library's in-process device group
+    (hvd_init_devices: one stream / pool / communicator per device, ncclCommInitAll), each driven by one thread of this
+    process -- what a hydrus user gets from HVD_DEVICES=0,1,...; same workloads, same JSON line, `"launch": "single-process"`."""
+    import threading
+
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    from hvd_amd import _lib as L
+    from hvd_amd.rendezvous import ThreadRendezvous
+
+    if L.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    devs = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devs) != args.gpus:
+        raise SystemExit(f"--devices lists {len(devs)} devices, --gpus says {args.gpus}")
+    L.init_devices(devs)
+    members = ThreadRendezvous.group(args.gpus)
+    failed = []
+
+    def body(r):
+        try:
+            L.set_context(r)
+            rank_main(args, r, r, args.gpus, real_stdout, members[r])
+        except BaseException as exc:  # noqa: BLE001 - any rank's failure fails the run (and must not strand the others)
+            import traceback
+
+            traceback.print_exc()
+            failed.append((r, repr(exc)))
+            members[r]._s.barrier.abort()
+
+    ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(1, args.gpus)]
+    for t in ts:
+        t.start()
+    body(0)
+    for t in ts:
+        t.join(600)
+    return 1 if failed or any(t.is_alive() for t in ts) else 0
+
+
+def rank_main(args, rank, local_rank, world, real_stdout, inproc):
+    """One rank of the bench: a process of its own (inproc is None: the default) or one thread of `--single-process`
+    (inproc = this rank's ThreadRendezvous; the library's current context is already this rank's)."""
     import hvd_amd
     from hvd_amd import _lib as L
     from hvd_amd import multigpu as M
@@ -282,16 +335,22 @@ def main():
     ndev = L.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    # one process per GPU: LOCAL_RANK picks the device; if the launcher masks devices per rank
-    # (HIP_VISIBLE_DEVICES), every rank sees a single device 0. HVD_FORCE_DEVICE: dev testing only.
-    dev = int(os.environ.get("HVD_FORCE_DEVICE", local_rank if local_rank < ndev else local_rank % ndev))
-    lib = L.init(dev)
-
-    rdzv = Rendezvous(rank, world)
     exchange, host_ex = None, None
     exchange_kind = "none"
     hard_exit = False  # a bootstrap thread stuck inside RCCL cannot be joined: leave with os._exit
-    if world > 1:
+    if inproc is not None:
+        lib = L.load()
+        rdzv = inproc
+        if world > 1:
+            exchange = M.GroupExchange(rank, world)
+            exchange_kind = "rccl" if L.group_exchange() == "rccl" else "host-memory (in-process group without RCCL: a device listed twice)"
+    else:
+        # one process per GPU: LOCAL_RANK picks the device; if the launcher masks devices per rank
+        # (HIP_VISIBLE_DEVICES), every rank sees a single device 0. HVD_FORCE_DEVICE: dev testing only.
+        dev = int(os.environ.get("HVD_FORCE_DEVICE", local_rank if local_rank < ndev else local_rank % ndev))
+        lib = L.init(dev)
+        rdzv = Rendezvous(rank, world)
+    if world > 1 and inproc is None:
         # ncclCommInitRank is collective and bounded, so that a hung bootstrap degrades to exchanging the candidates
         # over the control channel (reported in the JSON) instead of producing no measurement at all.
         exchange, why, hard_exit = M.connect_rccl(rdzv, float(os.environ.get("HVD_RCCL_INIT_TIMEOUT", "120")))
@@ -555,6 +614,8 @@ def main():
 
         def guarded():
             try:
+                if inproc is not None:
+                    L.set_context(rank)  # (the library's current context is per THREAD: this one starts on context 0)
                 run_extras()
             except BaseException as exc:  # noqa: BLE001 - reported in the JSON line
                 box["err"] = repr(exc)
@@ -573,6 +634,8 @@ def main():
 
     if rank != 0:
         if extras_note:  # do not enter another collective: rank 0 prints what it has
+            if inproc is not None:
+                return  # (a thread of the single process: rank 0's thread prints and ends the process)
             os._exit(0)
         if exchange is not None:
             exchange.close()
@@ -635,6 +698,8 @@ def main():
                    "n_hashes": n, "max_dist": 31, "kernel_variant": variant, "mode": args.mode,
                    "parallelism": f"tile-cyclic x{world}, DB replicated, exchange={exchange_kind}",
                    "exchange": exchange_kind, "rccl_ranks": world if exchange_kind == "rccl" else 0,
+                   "launch": "single process: the library's device group (hvd_init_devices), one thread per GPU" if inproc is not None
+                             else "one process per GPU",
                    "pairs_found": int(len(merged))},
         "roofline": roofline,
         "per_rank": head["per_rank"],

@@ -25,6 +25,7 @@ import socket
 import stat
 import struct
 import tempfile
+import threading
 import time
 
 _MAGIC = b"HVDRDZV2"
@@ -211,3 +212,48 @@ class Rendezvous:
                 os.unlink(self.path)
             except OSError:
                 pass
+
+
+class ThreadRendezvous:
+    """The same control-plane interface for the ranks of an IN-PROCESS device group (one thread per context:
+    hvd_init_devices, `bench.py --single-process`): all-gather of bytes through shared memory and a barrier. Make one group
+    with `ThreadRendezvous.group(world)` and hand member r to rank r's thread."""
+
+    class _Shared:
+        def __init__(self, world: int):
+            self.world = world
+            self.slots = [None] * world
+            self.barrier = threading.Barrier(world)
+
+    def __init__(self, rank: int, shared: "ThreadRendezvous._Shared"):
+        self.rank, self.world, self._s = rank, shared.world, shared
+
+    @classmethod
+    def group(cls, world: int) -> list["ThreadRendezvous"]:
+        shared = cls._Shared(world)
+        return [cls(r, shared) for r in range(world)]
+
+    def allgather(self, data: bytes) -> list[bytes]:
+        s = self._s
+        s.slots[self.rank] = bytes(data)
+        s.barrier.wait()
+        out = list(s.slots)
+        s.barrier.wait()  # nobody overwrites a slot before everybody has read all of them
+        return out
+
+    def barrier(self) -> None:
+        self._s.barrier.wait()
+
+    def broadcast(self, data: bytes | None, src: int = 0) -> bytes:
+        return self.allgather(data if self.rank == src else b"")[src]
+
+    def allreduce_max(self, values) -> list[float]:
+        vals = [float(v) for v in values]
+        parts = [struct.unpack(f"<{len(vals)}d", p) for p in self.allgather(struct.pack(f"<{len(vals)}d", *vals))]
+        return [max(col) for col in zip(*parts)]
+
+    def allreduce_min(self, values) -> list[float]:
+        return [-v for v in self.allreduce_max([-float(v) for v in values])]
+
+    def close(self) -> None:
+        pass

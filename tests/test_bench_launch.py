@@ -126,3 +126,20 @@ def test_bench_self_launch_propagates_a_rank_failure(gpu):
                    {"HVD_FORCE_DEVICE": "97"}, timeout=300)
     assert r.returncode != 0
     assert r.stdout.strip() == b""
+
+
+@pytest.mark.gpu
+def test_single_process_bench_runs_two_contexts_on_one_gpu():
+    """`python bench.py --gpus 2 --single-process --devices 0,0`: the two ranks are the two contexts of the library's
+    in-process device group (the mode the drop-in surfaces use under HVD_DEVICES), one thread each; device 0 listed twice,
+    so the candidates meet in host memory. One JSON line, exit code 0, the riding config-4 / config-5 legs included."""
+    r = _run_bench(["--gpus", "2", "--single-process", "--devices", "0,0", "--steps", "2", "--warmup", "1", "--hashes", "200000",
+                    "--cfg5-videos", "2000", "--no-cpu-baseline"], {}, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["launch"].startswith("single process")
+    assert out["config"]["exchange"].startswith("host-memory")
+    assert len(out["per_rank"]) == 2 and all(p["pairs"] > 0 for p in out["per_rank"])
+    assert out["config5"]["planted_recall"] == 1.0 and out["config4"]["pairs_found"] > 0
