@@ -216,3 +216,88 @@ def test_compiled_dct_table_is_the_host_matrix(hvd, oracle):
     _lib.check(_lib.load().hvd_dct_matrix(host.ctypes.data_as(C.c_void_p)))
     assert np.array_equal(host.view(np.uint32), baked)
     assert np.array_equal(oracle.dct_matrix().reshape(-1).view(np.uint32), baked)
+
+
+# ---------------------------------------------------------------- round 4: the in-process device group -------------------
+@pytest.mark.parametrize("variant", [9, 12, 13, 15])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_in_process_split_is_the_same_partition_for_every_form_the_probe_may_pick(hvd, world, variant):
+    """The contexts of a device group take tile (rb, cb) by (rb + cb) % world like the ranks of the process-per-GPU mode
+    (same kernel argument). The probe picks the form on the device, identically on every context (replicated DB); whatever
+    it picks, the shares must tile the upper triangle exactly once -- including the round-4 pair-queue form (15), whose
+    workgroup covers the fetch form's 1024 rows."""
+    from hvd_amd import multigpu as M
+
+    n = 70_000
+    assert M.tile_geometry(n, 15) == M.tile_geometry(n, 9)
+    area = 0
+    for r in range(world):
+        for row0, row1, col0, col1 in M.tiles_of_rank(n, r, world, variant=variant):
+            rows = np.arange(row0, row1)
+            area += int(np.clip(col1 - np.maximum(col0, rows + 1), 0, None).sum())
+    assert area == n * (n - 1) // 2
+
+
+def test_group_api_without_a_gpu_fails_loudly(hvd):
+    import ctypes as C
+
+    from hvd_amd import _lib
+
+    lib = _lib.load()
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible; the no-device path cannot be exercised here")
+    assert _lib.context_count() == 0 and _lib.group_exchange() == "none"
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.hvd_init_devices(devs, 2) == _lib.HVD_ERR_NO_DEVICE
+    assert lib.hvd_init_devices(devs, 0) == _lib.HVD_ERR_ARG and lib.hvd_init_devices(None, 2) == _lib.HVD_ERR_ARG
+    assert lib.hvd_init_devices(devs, 17) == _lib.HVD_ERR_ARG
+    assert lib.hvd_set_context(1) == _lib.HVD_ERR_ARG and lib.hvd_set_context(0) == _lib.HVD_OK
+    assert _lib.context_count() == 0
+    with pytest.raises(_lib.HvdError):
+        _lib.init_devices([0, 0])
+
+
+def test_hvd_devices_environment_is_parsed_before_any_device_is_touched(hvd, monkeypatch):
+    from hvd_amd import _lib
+
+    lib = _lib.load()
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible: hvd_init would bind it")
+    monkeypatch.setenv("HVD_DEVICES", "0,x")
+    assert lib.hvd_init(0) == _lib.HVD_ERR_ARG
+    monkeypatch.setenv("HVD_DEVICES", "1,0")  # the list must start with the device the caller asks for
+    assert lib.hvd_init(0) == _lib.HVD_ERR_ARG
+    monkeypatch.setenv("HVD_DEVICES", "0,1")
+    assert lib.hvd_init(0) == _lib.HVD_ERR_NO_DEVICE
+    monkeypatch.delenv("HVD_DEVICES")
+    assert lib.hvd_init(0) == _lib.HVD_ERR_NO_DEVICE
+
+
+def test_thread_rendezvous_is_a_rendezvous():
+    """The control plane of `bench.py --single-process` / the in-process ranks: same interface as the TCP rendezvous."""
+    import threading
+
+    from hvd_amd.rendezvous import ThreadRendezvous
+
+    world = 3
+    members = ThreadRendezvous.group(world)
+    out = [None] * world
+
+    def body(r):
+        m = members[r]
+        res = []
+        for k in range(50):
+            res.append(m.allgather(bytes([r, k])))
+            res.append(m.allreduce_max([r, -r, k * r]))
+            res.append(m.allreduce_min([r + k]))
+            res.append(m.broadcast(b"x%d" % k if r == 1 else None, src=1))
+            m.barrier()
+        out[r] = res
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert out[0] is not None and out[0] == out[1] == out[2]
+    assert out[0][0] == [b"\x00\x00", b"\x01\x00", b"\x02\x00"] and out[0][1] == [2.0, 0.0, 0.0] and out[0][3] == b"x0"
