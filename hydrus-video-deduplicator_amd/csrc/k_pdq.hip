@@ -1479,7 +1479,12 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
     // workgroups 51-52 us, 1792 54-55 us); dynamic: 7 per CU (the LDS limit; 1792 measured best); fma kernel: static, 7 per CU.
     // (16 k - 64 k frames: static stride over 7 per CU -- more workgroups than are resident, so the hardware's own
     // dispatch evens the load out: 20 k frames 97 -> 86 us)
-    const int64_t max_grid = n < 16384 ? 256 * 4 : 256 * 7;
+    // Round 4 (the waves of a workgroup no longer wait for each other): below 16 k frames the best static grid is k workgroups
+    // per CU with k such that ~60 % of them make a second trip -- 1500 groups: k = 4, 2048: 5, 2500: 6, 3000: 7
+    // (profiles/r04_k1_grid.txt: 10 k frames 51-53 us at k = 4, 47.9 us at k = 6) -- i.e. k = ceil(groups / (256 * 1.67)).
+    int64_t per_cu = (groups * 3 + 1279) / 1280;
+    per_cu = per_cu < 4 ? 4 : per_cu > 7 ? 7 : per_cu;
+    const int64_t max_grid = n < 16384 ? 256 * per_cu : 256 * 7;
     dim3 grid((unsigned)(nchunks < max_grid ? nchunks : max_grid));
     if (g_pdq_hash_grid > 0) grid.x = (unsigned)(nchunks < g_pdq_hash_grid ? nchunks : g_pdq_hash_grid);
     if (g_pdq_dct_mode == 1) {

@@ -14,12 +14,12 @@ for nf in [int(x) for x in os.environ.get("NS", "1000,4000,8192,10000,20000,6553
     for grid in [int(g) for g in os.environ.get("GRIDS", "0").split(",")]:
         L.check(lib.hvd_debug_set(b"pdq_hash_grid", grid))
         ks = []
-        for r in range(40):
+        for r in range(int(os.environ.get("REPS", 40))):
             L.check(lib.hvd_timer_start())
             L.check(lib.hvd_dev_pdq_hash_frames(d_f.ptr, nf, 64, 64, 1, None, d_h.ptr, d_q.ptr))
             ms = C.c_float(0)
             L.check(lib.hvd_timer_stop(C.byref(ms)))
-            if r >= 20:
+            if r >= int(os.environ.get("REPS", 40)) // 2:
                 ks.append(ms.value)
         print(f"n={nf:7d} grid {grid:5d}: {np.mean(ks) * 1e3:9.2f} us  {nf / np.mean(ks) * 1e3:.4g} frames/s", flush=True)
     d_f.free(); d_h.free(); d_q.free()
