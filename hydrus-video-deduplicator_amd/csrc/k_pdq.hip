@@ -1183,6 +1183,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
 #ifdef HVD_ABL_NOFETCH  // timing ablation only: every prefetch reads from a zero-byte resource
                             fbytes = 0;
 #endif
+#ifdef HVD_ABL_DMAFETCH  // timing ablation only (round 4, results wrong): the frame arrives through LDS-DMA instead -- whole
+                         // 128-byte lines, every byte requested exactly once: for every SECOND unit of a half, 32 rows x 384
+                         // bytes as 12 global_load_lds of 1 KB -- and the register fetch reads from a zero-byte resource.
+                         // Asks: is a duplicate-free, line-aligned DMA fetch (the structure VERDICT r3 next-3 proposes) worth
+                         // building? All instructions target one scratch KB of LDS; vmcnt waits fall where the real ones do.
+                            if (fbytes != 0 && CH == 3 && (((soff % row_bytes) / (2 * kWT * CH)) & 1u) == 0u) {
+                                const uint8_t* strip = frames + (size_t)fsel * frame_bytes + soff;
+#pragma unroll
+                                for (int i = 0; i < 12; ++i) {
+                                    const uint32_t piece = 64u * (uint32_t)i + (uint32_t)lane;
+                                    const uint8_t* src = strip + (size_t)(piece / 24u) * row_bytes + (piece % 24u) * 16u;
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                                     (__attribute__((address_space(3))) void*)park, 16, 0, 0);
+                                }
+                            }
+                            fbytes = 0;
+#endif
                             unit_fetch<CH>(make_rsrc(frames + (size_t)fsel * frame_bytes, fbytes), soff, lane, pre[par]);
                             wave_mem_sync();
                             if (half == hr) {
