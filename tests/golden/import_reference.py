@@ -18,6 +18,11 @@ What is measured (reference call sites in brackets):
                -> "le" (31 is a hit) or "lt"; compared with hvd_amd.vpdq.MATCH_COMPARATOR
   reduction    matchHash on an asymmetric pair (query 4 frames, 1 of which matches; target 2 frames, both match)
                -> which of min / max / query / target reproduces the number; compared with MATCH_POLICY
+  str grammar  str(VpdqHash) of a 2-frame hash and from_string(str(.)) round trip                    [hashing.py:30,40]
+               -> compared with hvd_amd.vpdq.VpdqHash's text form (the third declared assumption)
+  boundary     30 pairs of one-frame hashes at exactly 30 / 31 / 32 bits + 6 multi-frame pairs whose similarity hinges on
+               a frame pair at exactly 31: inputs and the reference's matchHash answers are stored (--write) as
+               tests/golden/reference_boundary.npz, which tests/test_gpu_round4.py replays through the GPU path
   frame hashes VideoHasher(1, 64|512, ...).hash_frame on this repo's seeded synthetic frames         [vpdqpy/vpdqpy.py:113-119]
                -> bit-exact vs oracle.hash_frames (strict and fma DCT modes), quality filter included
   testdb       (if <reference>/tests/testdb/videos exists and PyAV is importable) the reference's Vpdq.computeHash on
@@ -85,6 +90,49 @@ def main() -> int:
     if hvd_amd.vpdq.MATCH_POLICY not in fits:
         print(f"POLICY MISMATCH: reduction upstream is one of {fits}, default here is {hvd_amd.vpdq.MATCH_POLICY!r}")
         ok = False
+
+    # ---- str(VpdqHash): the text form the reference stores and parses (hashing.py:30,40) -------------------------------
+    two = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+    ref_text = str(frames_to_hash(two))
+    ours_text = str(hvd_amd.vpdq.VpdqHash(two.tobytes()))
+    round_trip = ref.VpdqHash.from_string(ref_text).bytes == two.tobytes()
+    parses_ours = None
+    try:
+        parses_ours = ref.VpdqHash.from_string(ours_text).bytes == two.tobytes()
+    except Exception as exc:  # noqa: BLE001
+        parses_ours = repr(exc)
+    report["str_grammar"] = {"reference": ref_text, "ours": ours_text, "equal": ref_text == ours_text,
+                             "reference_round_trip": round_trip, "reference_parses_ours": parses_ours,
+                             "ours_parses_reference": hvd_amd.vpdq.VpdqHash.from_string(ref_text).bytes == two.tobytes()}
+    if ref_text != ours_text:
+        print(f"GRAMMAR MISMATCH: str(VpdqHash) upstream is {ref_text[:80]!r}..., here {ours_text[:80]!r}...")
+        ok = False
+
+    # ---- boundary vectors: what the GPU suite replays ------------------------------------------------------------------
+    bq, bt, bsim, bdist = [], [], [], []
+    for d in (30, 31, 32):
+        for _ in range(10):
+            x = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+            y = synth.flip_bits(x, np.array([d]), rng)
+            bq.append(x)
+            bt.append(y)
+            bdist.append(d)
+            bsim.append(float(ref.matchHash(frames_to_hash(x), frames_to_hash(y), 31)))
+    mq, mt, msim = [], [], []
+    for k in range(6):  # multi-frame pairs: k+1 of the query's 6 frames have their only partner at exactly 31 bits
+        qv = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+        tv = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+        for f in range(min(k + 1, 5)):
+            tv[f] = synth.flip_bits(qv[f:f + 1], np.array([31]), rng)[0]
+        mq.append(qv)
+        mt.append(tv)
+        msim.append(float(ref.matchHash(frames_to_hash(qv), frames_to_hash(tv), 31)))
+    boundary = {"one_q": np.concatenate(bq), "one_t": np.concatenate(bt), "one_dist": np.array(bdist, dtype=np.int32),
+                "one_similarity": np.array(bsim), "multi_q": np.stack(mq), "multi_t": np.stack(mt),
+                "multi_similarity": np.array(msim), "tolerance": np.array([31], dtype=np.int32)}
+    report["boundary"] = {"one_frame": dict(zip(map(str, bdist), bsim)), "multi_frame_similarity": msim}
+    if args.write:
+        np.savez_compressed(os.path.join(HERE, "reference_boundary.npz"), **boundary)
 
     # ---- frame hashes -------------------------------------------------------------------------------------------------
     store = {}

@@ -205,3 +205,26 @@ def test_videohasher_two_hours_at_one_frame_per_second(gpu, hvd, oracle):
     got = h.finish()
     keep = want_q[order] >= 31
     assert len(got) == int(keep.sum()) and got.bytes == want_h[order][keep].tobytes()
+
+
+def test_reference_boundary_vectors_replay_on_the_gpu(gpu, hvd):
+    """tests/golden/import_reference.py --write (a container that has the hvdaccelerators wheel) stores the reference's own
+    matchHash answers for frame pairs at exactly 30 / 31 / 32 bits and for multi-frame pairs that hinge on a 31-bit pair.
+    Where that fixture exists it is replayed here through the GPU path with the reference's comparator and reduction; where
+    it does not (this repository as committed: the wheel is not installable offline) parity stays UNPINNED and the test says
+    so by skipping."""
+    import os
+
+    from conftest import GOLDEN
+
+    path = os.path.join(GOLDEN, "reference_boundary.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/reference_boundary.npz absent: run tests/golden/import_reference.py --write where the wheel exists")
+    g = np.load(path)
+    tol = int(g["tolerance"][0])
+    for x, y, want in zip(g["one_q"], g["one_t"], g["one_similarity"]):
+        got = hvd.matchHashBytes(x.tobytes(), y.tobytes(), tol)
+        assert abs(float(got) - float(want)) < 1e-6, (float(got), float(want))
+    for qv, tv, want in zip(g["multi_q"], g["multi_t"], g["multi_similarity"]):
+        got = hvd.matchHash(hvd.VpdqHash(qv.tobytes()), hvd.VpdqHash(tv.tobytes()), tol)
+        assert abs(float(got) - float(want)) < 1e-6, (float(got), float(want))
