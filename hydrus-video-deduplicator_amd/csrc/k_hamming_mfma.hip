@@ -984,7 +984,8 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
 // and the survivor density (per 1024-pair tile, as the probe estimates it) up to which it is preferred over the register form
 uint32_t g_mfma_queue_packed = 1;  // 0: the pair queue settles from the FP4 images even when packed hashes are at hand (tests)
 uint32_t g_mfma_auto_mid = 15;
-uint32_t g_mfma_auto_mid_max_x100 = 200;
+uint32_t g_mfma_auto_mid_max_x100 = 130;  // (scripts/gpu_k2_rate_sweep.py: the queue form wins up to ~1 survivor per tile -- 0.77-0.82 of the
+                                          // register form's time at 0.06-1.0 -- and loses from 2 on: 1.15x at 2, 2.4x at 4, the tile route)
 hipError_t launch_pack_fp4(const void* d_img, uint32_t n, void* d_db, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint64_t threads = (uint64_t)n * 8u;
