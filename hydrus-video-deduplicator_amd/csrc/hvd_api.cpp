@@ -535,6 +535,10 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_pdq_hash_grid = value;
         return HVD_OK;
     }
+    if (strcmp(key, "pdq_hash_prefetch") == 0) {  // 64x64 gray hash kernel, static launches: next frame fetched one frame ahead
+        hvd::g_pdq_hash_prefetch = value != 0;
+        return HVD_OK;
+    }
     if (strcmp(key, "pdq_luma_lut") == 0) {
         hvd::g_pdq_luma_lut = value;
         return HVD_OK;

@@ -81,6 +81,7 @@ void pdq_dct_table_copy(float* out_16x64);               // the compiled-in DCT 
 bool pdq_dct_table_matches(const float* host_16x64);  // the kernels' compile-time DCT table vs the host's computation
 extern int g_pdq_luma_lut;
 extern int g_pdq_hash_grid;
+extern int g_pdq_hash_prefetch;
 extern int g_pdq_dct_mode;
 extern bool g_pdq_fused_down512;
 extern int g_pdq_down512_wave;

@@ -120,7 +120,11 @@ __device__ __forceinline__ void wave_lds_handover() {
 // a launch starts -- which is why launches below 64 k frames keep the static stride (work == nullptr): measured, the draws cost
 // 10 k frames 52 -> 65 us, while 400 k frames gain 12 % (profiles/r03_k1_grid.txt). Every trip draws exactly once, so the draw that returns (trips - 1) is the last of the launch: its
 // workgroup zeroes the counter for the next launch that is handed this slot -- no exit counter.
-template <int KIND, int DLDS, int LUT>
+// PREF (gray bytes, static stride only -- the launches below 64 k frames): the wave's NEXT frame is fetched while it works
+// on this one, as four 16-byte loads per lane (16 VGPRs in flight for a whole frame's time), handed to the lanes through
+// the wave's own T area (4 096 of its 4 352 bytes; T is written only after the last byte has been read) -- instead of 64
+// byte loads per lane whose latency every frame started with (the fma kernel has worked this way since round 2).
+template <int KIND, int DLDS, int LUT, bool PREF = false>
 __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in, long long n,
                                                     const float* __restrict__ dct, uint8_t* __restrict__ hashes,
                                                     int32_t* __restrict__ quality, unsigned int* __restrict__ work,
@@ -137,6 +141,14 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
 
     const long long groups = (n + kWaves - 1) / kWaves;
     const long long nchunks = (groups + chunk - 1) / chunk;
+    uint4 nb0 = make_uint4(0, 0, 0, 0), nb1 = nb0, nb2 = nb0, nb3 = nb0;  // PREF: the next frame's bytes, in flight
+    if (PREF) {
+        const long long f0 = (long long)blockIdx.x * kWaves + wave;
+        if ((long long)blockIdx.x < groups && f0 < n) {
+            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + f0 * 4096);
+            nb0 = src[lane]; nb1 = src[64 + lane]; nb2 = src[128 + lane]; nb3 = src[192 + lane];
+        }
+    }
     for (long long ck = blockIdx.x; ck < nchunks;) {
         unsigned int drawn = 0;
         if (work != nullptr && threadIdx.x == 0) drawn = atomicAdd(&work[0], 1u);  // consumed behind this trip's last group
@@ -147,7 +159,20 @@ __global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in,
         if (valid) {
             // ---- stage 0: column `lane` of the frame -------------------------------
             float a[64];
-            if (KIND == 0) {
+            if (KIND == 0 && PREF) {
+                uint4* dstb = reinterpret_cast<uint4*>(&lds.T[wave][0][0]);
+                dstb[lane] = nb0; dstb[64 + lane] = nb1; dstb[128 + lane] = nb2; dstb[192 + lane] = nb3;
+                const long long fn = (g + gridDim.x) * kWaves + wave;  // (static stride, one group per trip)
+                if (g + gridDim.x < groups && fn < n) {
+                    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + fn * 4096);
+                    nb0 = src[lane]; nb1 = src[64 + lane]; nb2 = src[128 + lane]; nb3 = src[192 + lane];
+                }
+                wave_lds_handover();
+                const uint8_t* srcb = reinterpret_cast<const uint8_t*>(&lds.T[wave][0][0]) + lane;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) a[k] = lds.luma_lut[srcb[k * 64]];
+                wave_lds_handover();  // every byte has been read before stage 1 writes T over them
+            } else if (KIND == 0) {
                 const uint8_t* src = reinterpret_cast<const uint8_t*>(in) + f * 4096 + lane;
 #pragma unroll
                 for (int k = 0; k < 64; ++k) {
@@ -1512,7 +1537,11 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
         return hipGetLastError();
     }
 #define HVD_K1(KIND, D, L) hipLaunchKernelGGL((k_pdq_hash64<KIND, D, L>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality, work, chunk)
-    if (kind == 0) {
+#define HVD_K1P(D) hipLaunchKernelGGL((k_pdq_hash64<0, D, 1, true>), grid, dim3(256), 0, s, d_in, (long long)n, d_dct, d_hashes, d_quality, work, chunk)
+    if (kind == 0 && !dynamic && g_pdq_hash_prefetch && lut == 1 && dlds != 1) {
+        if (dlds == 2) HVD_K1P(2);
+        else HVD_K1P(0);
+    } else if (kind == 0) {
         if (dlds == 2) HVD_K1(0, 2, 1);
         else if (dlds == 1) HVD_K1(0, 1, 1);
         else if (lut == 0) HVD_K1(0, 0, 0);
@@ -1524,9 +1553,12 @@ hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float*
         else HVD_K1(1, 0, 0);
     }
 #undef HVD_K1
+#undef HVD_K1P
     return hipGetLastError();
 }
 
+int g_pdq_hash_prefetch = 0;  // A/B switch (hvd_debug_set "pdq_hash_prefetch"): measured SLOWER (115 VGPRs = 4 waves per SIMD instead of 5:
+                              // 10 k frames 47.6 -> 50.2 us, profiles/r04_k1_grid.txt), so off; bit-identical either way
 static int jarosz_window(int dim) { return (dim + 2 * 64 - 1) / (2 * 64); }
 
 // Workspace (floats per frame) the down-sampler needs besides the 64x64 output.
