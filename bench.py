@@ -530,6 +530,12 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                         "value": sig(n4 * (n4 - 1) / 2 / r4["elapsed"], 5), "unit": "comparisons/s", "n_gpus": world,
                         "seconds": round(r4["elapsed"], 4), "pairs_found": int(len(r4["merged"])),
                         "per_rank": r4["per_rank"],
+                        "roofline": (lambda kms: {"bound": "mfma", "kernel": "k_allpairs_mfma (form chosen by the probe; first-stage MFMAs: 256 flop per comparison)",
+                                                  "achieved": sig(n4 * (n4 - 1) / 2 / world * 256.0 / (kms * 1e-3) / 1e12), "peak": FP4_PEAK_TFLOPS,
+                                                  "unit": "TFLOP/s", "frac": round(n4 * (n4 - 1) / 2 / world * 256.0 / (kms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS, 4),
+                                                  "kernel_ms": round(kms, 3), "traffic": None,
+                                                  "basis": "one rank's share of the comparisons over the slowest rank's kernel time (HIP events)"})(
+                            max(p_["kernel_ms"] for p_ in r4["per_rank"])),
                         "gate": "every planted pair within tolerance reported; every reported pair re-verified on the host"}
                 del r4
         if not args.no_extras and (world == 1 or exchange is not None):  # the hash-shard exchange needs RCCL

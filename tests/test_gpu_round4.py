@@ -228,3 +228,20 @@ def test_reference_boundary_vectors_replay_on_the_gpu(gpu, hvd):
     for qv, tv, want in zip(g["multi_q"], g["multi_t"], g["multi_similarity"]):
         got = hvd.matchHash(hvd.VpdqHash(qv.tobytes()), hvd.VpdqHash(tv.tobytes()), tol)
         assert abs(float(got) - float(want)) < 1e-6, (float(got), float(want))
+
+
+def test_k1_next_frame_prefetch_switch_is_bit_identical(gpu, hvd, oracle):
+    """The static launches of the 64x64 hash kernel can fetch the next frame one frame ahead (hvd_debug_set
+    "pdq_hash_prefetch"; off by default: measured slower, profiles/r04_k1_grid.txt). Either way the bits are the oracle's,
+    at a size where workgroups make several trips and at one where the last trip is ragged."""
+    lib = gpu.load()
+    for n in (10_000, 4_099):
+        fr = hvd.synth.frames_gray(n, seed=71)
+        wh, wq = oracle.hash_frames(fr, num_threads=8)
+        for pref in (1, 0):
+            gpu.check(lib.hvd_debug_set(b"pdq_hash_prefetch", pref))
+            try:
+                h, q = hvd.vpdq.hash_frames(fr)
+            finally:
+                gpu.check(lib.hvd_debug_set(b"pdq_hash_prefetch", 0))
+            assert np.array_equal(h, wh) and np.array_equal(q, wq), (n, pref)
