@@ -388,7 +388,10 @@ __device__ __noinline__ void panel_survivors(uint32_t marks, const uint4* __rest
 constexpr uint32_t kQTileLanes = 4;   // a tile with survivors in more lanes (columns x halves) than this takes the tile route (4e-4 of the surviving tiles of frame hashes)
 constexpr uint32_t kQSuperMax = (kSuper / 32) * 8 * kQTileLanes;  // most that one wave can add between two barriers
 constexpr uint32_t kQWaveCap = 256 + kQSuperMax;                  // entries per wave
-constexpr uint32_t kQDrainAt = 700;   // settle when the workgroup holds this many: one round of drain_queues_wg (3 x 256) with the next super-panel's ~30 on top
+#ifndef HVD_K2_QDRAIN_AT
+#define HVD_K2_QDRAIN_AT 700
+#endif
+constexpr uint32_t kQDrainAt = HVD_K2_QDRAIN_AT;   // settle when the workgroup holds this many: one round of drain_queues_wg (3 x 256) with the next super-panel's ~30 on top
 // entry: x = group mask of the lane's accumulator registers (bit 5 - g <-> a survivor among the registers of group g, see
 // or16_groups) | (first row of the tile, relative to the WAVE's first row: 32 t) << 16 (the wave is the queue's index);
 // y = column (absolute) << 1 | h (the lane's half: its rows start 4 h below the tile's first) -- hence n_pad < 2^31
