@@ -338,28 +338,34 @@ int hvd_init_devices(const int* devices, int n_devices) {
             ncclResult_t r = ncclCommInitAll(comms, n_devices, devices);
             if (r == ncclSuccess) {
                 const int saved = t_ctx;
+                for (int i = 0; i < n_devices; ++i) {  // every communicator has an owner first (so that a failure below aborts all)
+                    g_ctx[i].comm = comms[i];
+                    g_ctx[i].comm_ready = true;
+                }
                 for (int i = 0; i < n_devices && rccl; ++i) {
                     t_ctx = i;
                     (void)hipSetDevice(g.device);
-                    g.comm = comms[i];
                     g.rank = i;
                     g.world = n_devices;
                     if (hipMalloc(&g.x_cnt_in, 16) != hipSuccess || hipMalloc(&g.x_cnt_all, 16 * (size_t)n_devices) != hipSuccess) rccl = false;
-                    g.comm_ready = true;
                 }
                 t_ctx = saved;
             } else {
                 rccl = false;
             }
-            if (!rccl)
+            if (!rccl) {
+                const int saved = t_ctx;
                 for (int i = 0; i < n_devices; ++i)
                     if (g_ctx[i].comm_ready) {
                         t_ctx = i;
+                        (void)hipSetDevice(g.device);
                         free_exchange_buffers();
                         (void)ncclCommAbort(g.comm);
                         g.comm_ready = false;
-                        t_ctx = 0;
                     }
+                t_ctx = saved;
+                (void)hipGetLastError();
+            }
         }
         g_group_rccl = rccl;
         for (int i = 0; i < n_devices; ++i) {
