@@ -124,8 +124,13 @@ __device__ __forceinline__ void wave_lds_handover() {
 // on this one, as four 16-byte loads per lane (16 VGPRs in flight for a whole frame's time), handed to the lanes through
 // the wave's own T area (4 096 of its 4 352 bytes; T is written only after the last byte has been read) -- instead of 64
 // byte loads per lane whose latency every frame started with (the fma kernel has worked this way since round 2).
+#ifdef HVD_K1_WAVES  // A/B builds: force the strict hash kernel to this many waves per SIMD (profiles/r04_k1_grid.txt)
+#define HVD_K1_OCC __attribute__((amdgpu_waves_per_eu(HVD_K1_WAVES, HVD_K1_WAVES)))
+#else
+#define HVD_K1_OCC
+#endif
 template <int KIND, int DLDS, int LUT, bool PREF = false>
-__global__ __launch_bounds__(256) void k_pdq_hash64(const void* __restrict__ in, long long n,
+__global__ __launch_bounds__(256) HVD_K1_OCC void k_pdq_hash64(const void* __restrict__ in, long long n,
                                                     const float* __restrict__ dct, uint8_t* __restrict__ hashes,
                                                     int32_t* __restrict__ quality, unsigned int* __restrict__ work,
                                                     int chunk) {
