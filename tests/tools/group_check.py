@@ -38,6 +38,11 @@ want = O.allpairs(db, 31, num_threads=8)
 assert len(want) > 500
 got = hvd_amd.allpairs_hamming(db, 31)  # first try with a buffer that is too small: the true total comes back, then all of it
 assert np.array_equal(got, want)
+# a buffer that is too small: every context sees the same TRUE total, none truncates it, nobody is left in the exchange
+small = np.zeros(10, dtype=L.PAIR_DTYPE)
+cnt = C.c_int64(0)
+rc = lib.hvd_allpairs_hamming256(db.ctypes.data, len(db), None, 31, small.ctypes.data, 10, C.byref(cnt))
+assert rc == L.HVD_ERR_OVERFLOW and cnt.value == len(want), (rc, cnt.value, len(want))
 grp = np.sort(np.random.default_rng(62).integers(0, 5000, len(db)).astype(np.int32))
 assert np.array_equal(hvd_amd.allpairs_hamming(db, 31, group=grp), O.allpairs(db, 31, group=grp, num_threads=8))
 # every tile belongs to exactly one context: each context's own share, launched by hand, partitions the result
