@@ -564,6 +564,11 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_mfma_auto_mid = (uint32_t)value;
         return HVD_OK;
     }
+    if (strcmp(key, "mfma_lds_pad") == 0) {  // occupancy experiments: bytes of unused dynamic LDS per workgroup of the FP4-MFMA kernels
+        if (value < 0 || value > 65536) return fail(HVD_ERR_ARG, "mfma_lds_pad: 0..65536 bytes");
+        hvd::g_mfma_lds_pad = (uint32_t)value;
+        return HVD_OK;
+    }
     if (strcmp(key, "mfma_queue_packed") == 0) {  // 0: the pair-queue form settles its candidates from the FP4 images only
         hvd::g_mfma_queue_packed = value != 0;
         return HVD_OK;

@@ -985,6 +985,7 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
 
 // auto variant (13): the form for data with common false survivors (15 = pair queue; 0 = none, i.e. round 3's two-way choice)
 // and the survivor density (per 1024-pair tile, as the probe estimates it) up to which it is preferred over the register form
+uint32_t g_mfma_lds_pad = 0;  // occupancy experiments: unused dynamic LDS per workgroup (hvd_debug_set "mfma_lds_pad")
 uint32_t g_mfma_queue_packed = 1;  // 0: the pair queue settles from the FP4 images even when packed hashes are at hand (tests)
 uint32_t g_mfma_auto_mid = 15;
 uint32_t g_mfma_auto_mid_max_x100 = 130;  // (scripts/gpu_k2_rate_sweep.py: the queue form wins up to ~1 survivor per tile -- 0.77-0.82 of the
@@ -1089,11 +1090,11 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
     HitCtx* ctx = reinterpret_cast<HitCtx*>(buf + 16);
     hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1, rect ? d_img_q : d_img, d_img));
     if (rect)
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE>), grid, dim3(256), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
                            select_id);
     else
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE>), grid, dim3(256), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)nullptr, fp4_scale2(), ctx, d_select,
                            select_id);
     return hipGetLastError();
