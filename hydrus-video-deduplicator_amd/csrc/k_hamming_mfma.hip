@@ -265,7 +265,7 @@ __device__ __forceinline__ HitCtx load_ctx(const HitCtx* ctx) {
 // out of line it does not disturb the register allocation of the loop (inlined it cost the fetch form 6 VGPRs = one
 // resident wave per SIMD).
 // (tid is an argument: a callee that reads threadIdx makes the caller keep the packed work-item ids alive in v31.)
-__device__ __noinline__ void flush_pairs_wg(const HitCtx* __restrict__ ctx, uint32_t tid) {
+__device__ __noinline__ void flush_pairs_wg(const HitCtx* __restrict__ ctx, uint32_t tid, uint32_t nthreads) {
     __shared__ unsigned long long base_s;
     const uint32_t m = min(g_wg_npairs, kWgPairs);
     if (m == 0u) return;  // uniform over the workgroup
@@ -273,7 +273,7 @@ __device__ __noinline__ void flush_pairs_wg(const HitCtx* __restrict__ ctx, uint
     if (tid == 0u) base_s = atomicAdd(c.count, (unsigned long long)m);
     __syncthreads();
     const unsigned long long base = base_s;
-    for (uint32_t k = tid; k < m; k += 256u)
+    for (uint32_t k = tid; k < m; k += nthreads)
         if (base + k < c.cap) c.out[base + k] = g_wg_pairs[k];
 }
 
@@ -386,8 +386,8 @@ __device__ __noinline__ void panel_survivors(uint32_t marks, const uint4* __rest
 // three siblings run into the next barrier and wait for it (first version: SQ_WAIT_ANY +50 %, matrix pipe 0.50 busy). Behind
 // a barrier everybody is in step anyway; 256 lanes take one entry each, one round trip, every ~7 super-panels.
 constexpr uint32_t kQTileLanes = 4;   // a tile with survivors in more lanes (columns x halves) than this takes the tile route (4e-4 of the surviving tiles of frame hashes)
-constexpr uint32_t kQSuperMax = (kSuper / 32) * 8 * kQTileLanes;  // most that one wave can add between two barriers
-constexpr uint32_t kQWaveCap = 256 + kQSuperMax;                  // entries per wave
+constexpr uint32_t kQEntries = 1536;  // entries of all the workgroup's queues together (12 KB): 4 waves x 384 or 8 waves x 192
+constexpr uint32_t kQMaxWaves = 8;
 #ifndef HVD_K2_QDRAIN_AT
 #define HVD_K2_QDRAIN_AT 700
 #endif
@@ -395,8 +395,8 @@ constexpr uint32_t kQDrainAt = HVD_K2_QDRAIN_AT;   // settle when the workgroup 
 // entry: x = group mask of the lane's accumulator registers (bit 5 - g <-> a survivor among the registers of group g, see
 // or16_groups) | (first row of the tile, relative to the WAVE's first row: 32 t) << 16 (the wave is the queue's index);
 // y = column (absolute) << 1 | h (the lane's half: its rows start 4 h below the tile's first) -- hence n_pad < 2^31
-__shared__ uint2 g_wave_queue[4][kQWaveCap];
-__shared__ __attribute__((aligned(16))) uint32_t g_wave_qn[4];
+__shared__ uint2 g_wave_queue[kQEntries];  // wave w's queue: [w * qcap, (w + 1) * qcap), qcap = kQEntries / waves
+__shared__ __attribute__((aligned(16))) uint32_t g_wave_qn[kQMaxWaves];
 
 __device__ __forceinline__ uint32_t sign_popc(const uint4& x, const uint4& y, uint32_t acc) {
     // FP4 images: equal magnitude bits cancel, only sign nibbles survive the XOR (rows beyond n are FP4 zeros -- filtered
@@ -436,15 +436,42 @@ __device__ __forceinline__ void settle_pair(const HitCtx& c, uint32_t i, uint32_
     }
 }
 
-// thread tid's share of the queues: entry number k of the concatenation (wave 0's entries, wave 1's, ...); *w = the wave
-__device__ __forceinline__ uint2* queue_entry(uint32_t k, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t* w_out) {
-    const uint32_t w = k < n0 ? 0u : k < n0 + n1 ? 1u : k < n0 + n1 + n2 ? 2u : 3u;
-    const uint32_t idx = k - (w == 0u ? 0u : w == 1u ? n0 : w == 2u ? n0 + n1 : n0 + n1 + n2);
+// The fill levels of the workgroup's queues as every thread sees them behind a barrier (wave-uniform scalars): pre[w] = number
+// of entries in front of wave w's in the concatenation (wave 0's entries, wave 1's, ...), pre[kQMaxWaves] = all of them.
+struct QCounts {
+    uint32_t pre[kQMaxWaves + 1];
+};
+__device__ __forceinline__ QCounts load_qcounts(uint32_t waves) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(&g_wave_qn[0]), hi = *reinterpret_cast<const uint4*>(&g_wave_qn[4]);
+    const uint32_t raw[kQMaxWaves] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    QCounts c;
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kQMaxWaves; ++w) {
+        c.pre[w] = run;
+#if defined(__HIP_DEVICE_COMPILE__)
+        run += w < waves ? (uint32_t)__builtin_amdgcn_readfirstlane((int)raw[w]) : 0u;
+#else
+        run += w < waves ? raw[w] : 0u;
+#endif
+    }
+    c.pre[kQMaxWaves] = run;
+    return c;
+}
+// entry number k (< pre[kQMaxWaves]) of the concatenation; *w_out = the wave it belongs to
+__device__ __forceinline__ uint2* queue_entry(uint32_t k, const QCounts& c, uint32_t qcap, uint32_t* w_out) {
+    uint32_t w = 0, base = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < kQMaxWaves; ++i) {
+        const bool past = k >= c.pre[i];  // (pre is non-decreasing; empty and absent waves share their successor's value)
+        w = past ? i : w;
+        base = past ? c.pre[i] : base;
+    }
     *w_out = w;
-    return &g_wave_queue[w][idx];
+    return &g_wave_queue[w * qcap + (k - base)];
 }
 
-// Settling the four queues (n0..n3 entries) takes two LEAF functions, both called by all 256 threads behind a barrier (the
+// Settling the workgroup's queues takes two LEAF functions, both called by all of its threads behind a barrier (the
 // caller puts another barrier behind them before anybody pushes again). Leaf, because a function that calls another keeps
 // its own values in the high callee-saved registers, and every register a callee touches is one the kernel cannot hold a
 // live value in across the call (a first version with nested calls: 167 VGPRs, 39 spills in the kernel's panel loop).
@@ -462,23 +489,22 @@ __device__ __forceinline__ uint2* queue_entry(uint32_t k, uint32_t n0, uint32_t 
 // 2. settle_marked_wg, which walks the same entries again: the rows that passed in full (settle_pair), an entry's further
 //    groups through the same filter first (rows_lds is still valid). Without packed hashes (image-only callers) every row
 //    of every group is its work.
-__device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx, uint32_t n0_v, uint32_t n1_v, uint32_t n2_v,
-                                                 uint32_t n3_v, uint32_t row0_v, uint32_t other_half_v, uint32_t tid,
-                                                 uint4* rows_generic) {
+__device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx, uint32_t geom_v, uint32_t row0_v,
+                                                 uint32_t other_half_v, uint32_t tid, uint4* rows_generic) {
 #if defined(__HIP_DEVICE_COMPILE__)
     auto* rows_lds = (__attribute__((address_space(3))) uint4*)rows_generic;  // (ds_* instead of flat_* accesses)
-    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0_v), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1_v);
-    const uint32_t n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n2_v), n3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n3_v);
+    const uint32_t geom = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom_v);
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
     const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
     const auto* cc = (const __attribute__((address_space(4))) HitCtx*)uniform_u64((unsigned long long)ctx);
 #else
     uint4* rows_lds = rows_generic;
-    const uint32_t n0 = n0_v, n1 = n1_v, n2 = n2_v, n3 = n3_v, row0 = row0_v, ohw = other_half_v;
+    const uint32_t geom = geom_v, row0 = row0_v, ohw = other_half_v;
     const HitCtx* cc = ctx;
 #endif
-    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
-    const uint32_t total = n0 + n1 + n2 + n3;
+    const uint32_t waves = geom & 15u, qcap = geom >> 8, nthreads = 64u * waves;  // waves | entries per wave << 8
+    const QCounts qc = load_qcounts(waves);
+    const uint32_t total = qc.pre[kQMaxWaves];
     const uint4* __restrict__ db_q = cc->db_q;
     const uint4* __restrict__ db_t = cc->db_t;
     const uint32_t max_dist = cc->max_dist;
@@ -486,29 +512,27 @@ __device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx,
 #if defined(HVD_K2_QABL) && HVD_K2_QABL == 6  // timing-only ablation: the call and nothing else
     return 0u;
 #endif
+    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
     {
         const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;  // rows beyond it are padding: never queued, never read
 #pragma unroll
-        for (uint32_t q = 0; q < kSuper * 8u / 256u; ++q) {
-            const uint32_t r = tid + 256u * q;
-            rows_lds[r] = db_q[(size_t)min(row0 + r, last) * 2u + oh];
-        }
+        for (uint32_t r = tid; r < kSuper * 8u; r += nthreads) rows_lds[r] = db_q[(size_t)min(row0 + r, last) * 2u + oh];
         __syncthreads();
     }
     constexpr int E = 3;
     uint32_t left = 0;
 #pragma unroll 1
-    for (uint32_t k0 = 0; k0 < total; k0 += 256u * E) {
+    for (uint32_t k0 = 0; k0 < total; k0 += nthreads * E) {
         uint32_t ex[E];
         uint4 col[E];
 #pragma unroll
         for (int u = 0; u < E; ++u) {
-            const uint32_t k = k0 + tid + 256u * (uint32_t)u;
+            const uint32_t k = k0 + tid + nthreads * (uint32_t)u;
             ex[u] = 0u;
             col[u] = make_uint4(0u, 0u, 0u, 0u);
             if (k < total) {
                 uint32_t w;
-                const uint2 e = *queue_entry(k, n0, n1, n2, &w);
+                const uint2 e = *queue_entry(k, qc, qcap, &w);
                 // (bits 15, 12..14 are free: h and the wave ride along so that y and w need not be held)
                 ex[u] = e.x | ((e.y & 1u) << 15) | (w << 12);
                 col[u] = db_t[(size_t)(e.y >> 1) * 2u + oh];
@@ -516,13 +540,13 @@ __device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx,
         }
 #pragma unroll
         for (int u = 0; u < E; ++u) {
-            const uint32_t k = k0 + tid + 256u * (uint32_t)u;
+            const uint32_t k = k0 + tid + nthreads * (uint32_t)u;
             if (k >= total) continue;
             const uint32_t gm = ex[u] & 63u;
             const uint32_t first = 31u - (uint32_t)__clz((int)gm);
             const uint32_t rest = gm & ~(1u << first);
             const uint32_t g = 5u - first, r0 = 3u * g;
-            const uint32_t ibrel = (ex[u] >> 16) + 4u * ((ex[u] >> 15) & 1u) + wrows * ((ex[u] >> 12) & 3u);  // relative to row0
+            const uint32_t ibrel = (ex[u] >> 16) + 4u * ((ex[u] >> 15) & 1u) + wrows * ((ex[u] >> 12) & 7u);  // relative to row0
             // (group 5 = register 15 alone: its row three times)
             const uint4 x0 = rows_lds[qrow_of(ibrel, r0)], x1 = rows_lds[qrow_of(ibrel, g == 5u ? r0 : r0 + 1u)],
                         x2 = rows_lds[qrow_of(ibrel, g == 5u ? r0 : r0 + 2u)];
@@ -531,7 +555,7 @@ __device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx,
             if (g == 5u) pass &= 1u;
             left |= pass | rest;
             uint32_t w_;
-            queue_entry(k, n0, n1, n2, &w_)->x = (ex[u] & 0xFFFF0000u) | rest | (pass << 6) | (g << 9);
+            queue_entry(k, qc, qcap, &w_)->x = (ex[u] & 0xFFFF0000u) | rest | (pass << 6) | (g << 9);
         }
     }
 #if defined(HVD_K2_QABL) && HVD_K2_QABL == 7  // timing-only ablation: the filter runs, nothing is settled
@@ -540,27 +564,27 @@ __device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx,
     return left;
 }
 
-__device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, uint32_t n0_v, uint32_t n1_v, uint32_t n2_v,
-                                              uint32_t n3_v, uint32_t row0_v, uint32_t other_half_v, uint32_t tid,
-                                              const uint4* rows_generic) {
+__device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, uint32_t geom_v, uint32_t row0_v,
+                                              uint32_t other_half_v, uint32_t tid, const uint4* rows_generic) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const auto* rows_lds = (const __attribute__((address_space(3))) uint4*)rows_generic;
-    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n0_v), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1_v);
-    const uint32_t n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n2_v), n3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n3_v);
+    const uint32_t geom = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom_v);
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
     const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
 #else
     const uint4* rows_lds = rows_generic;
-    const uint32_t n0 = n0_v, n1 = n1_v, n2 = n2_v, n3 = n3_v, row0 = row0_v, ohw = other_half_v;
+    const uint32_t geom = geom_v, row0 = row0_v, ohw = other_half_v;
 #endif
     const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
+    const uint32_t waves = geom & 15u, qcap = geom >> 8, nthreads = 64u * waves;
+    const QCounts qc = load_qcounts(waves);
     const HitCtx c = load_ctx(ctx);
-    const uint32_t total = n0 + n1 + n2 + n3;
+    const uint32_t total = qc.pre[kQMaxWaves];
     const bool packed = c.db_t != nullptr;
 #pragma unroll 1
-    for (uint32_t k = tid; k < total; k += 256u) {
+    for (uint32_t k = tid; k < total; k += nthreads) {
         uint32_t w;
-        const uint2 e = *queue_entry(k, n0, n1, n2, &w);
+        const uint2 e = *queue_entry(k, qc, qcap, &w);
         const uint32_t ibrel = (e.x >> 16) + 4u * (e.y & 1u) + wrows * w, j = e.y >> 1;
         uint32_t gm = e.x & 63u, pass = (e.x >> 6) & 7u;
         if ((gm | pass) == 0u) continue;
@@ -593,11 +617,12 @@ __device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, ui
 // wave-uniform LDS base + lane*16, no VGPR round trip (so nothing to keep live -- or spill --
 // across the compute phase). The data is complete after the vmcnt(0) that hipcc places in
 // front of the next __syncthreads().
+template <int WAVES>
 __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src, uint4* lds_dst, uint32_t wave,
                                                   uint32_t lane) {
 #pragma unroll
-    for (int q = 0; q < kSuper * 8 / 256; ++q) {
-        const uint32_t chunk0 = (uint32_t)q * 256u + wave * 64u;  // first 16-B chunk of this wave-instruction
+    for (int q = 0; q < kSuper * 8 / (64 * WAVES); ++q) {
+        const uint32_t chunk0 = (uint32_t)q * (64u * WAVES) + wave * 64u;  // first 16-B chunk of this wave-instruction
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + chunk0 + lane),
             (__attribute__((address_space(3))) void*)(lds_dst + chunk0), 16, 0, 0);
@@ -619,9 +644,12 @@ __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src,
 // query image img_q (nq hashes), candidates from the target image img (n hashes), full rectangle.
 //   QUEUE  (NBR = S1 = 2 only) first-stage survivors are settled pair by pair on the VALU (pair queue, above) instead of
 //          tile by tile on the matrix pipe: the form for data on which false survivors are common (real frame hashes).
-template <int TILES, int NBR, int S1, bool RECT, bool QUEUE = false>
+//   WAVES  waves per workgroup: 4, or 8 (QUEUE with 4 tiles per wave: the same 1024 rows per workgroup and the same panels
+//          shared by twice as many, lighter waves -- <= 128 VGPRs = FOUR resident waves per SIMD. The pair-queue form lives on
+//          resident waves: 1 / 2 / 3 per SIMD take 40.6 / 23.0 / 18.2 ms on frame hashes, profiles/r04_k2_queue_ablation.txt).
+template <int TILES, int NBR, int S1, bool RECT, bool QUEUE = false, int WAVES = 4>
 // (the 4-tile register form is held to 3 waves per SIMD = 168 VGPRs: with the pre-read fragment it would take 170)
-__global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
                                                           uint32_t max_dist, uint32_t col_chunk, uint32_t rank,
                                                           uint32_t world, const uint4* __restrict__ img_q, float scale2,
                                                           const HitCtx* __restrict__ ctx,
@@ -629,7 +657,11 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
     static_assert(S1 == 2 || S1 == 4, "first stage = 128 or 256 bits");
     static_assert(NBR >= S1 && (NBR == 2 || NBR == 4), "register-resident k-steps");
     static_assert(!QUEUE || (NBR == 2 && S1 == 2 && TILES <= 8), "the pair queue belongs to the 128-bit fetch form");
-    constexpr uint32_t WROWS = 32u * TILES, ROWS = 4u * WROWS;
+    static_assert(WAVES == 4 || (WAVES == 8 && QUEUE), "8-wave workgroups exist for the pair-queue form");
+    constexpr uint32_t WROWS = 32u * TILES, ROWS = (uint32_t)WAVES * WROWS, NT = 64u * WAVES;
+    // QUEUE: entries per wave, and the most one wave can add between two barriers
+    constexpr uint32_t QCAP = kQEntries / WAVES, QSUPERMAX = (kSuper / 32) * TILES * kQTileLanes;
+    static_assert(!QUEUE || QCAP >= QSUPERMAX + 64, "a wave's queue must take a super-panel's worth on top of a carry-over");
     __shared__ uint4 lds0[kSuper * 8], lds1[kSuper * 8];
 
     // data-dependent choice between two forms of this kernel (launch_allpairs_auto): both are launched, the
@@ -693,7 +725,7 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
     const v16f zero = {c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1, c1};  // the accumulators' start value
     // QUEUE: index of this wave's next free slot in the (flattened) queue array (wave-uniform) -- the fill level and the
     // wave's base in one scalar -- and this lane's share of an entry's y word: (column << 1) | h
-    uint32_t qidx = wave * kQWaveCap;
+    uint32_t qidx = wave * QCAP;
     const uint32_t qcol = (li << 1) | h;
 
     // The two LDS buffers are separate objects and the super-panel loop is unrolled by two, so that every
@@ -759,7 +791,7 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
                         // reload whose vmcnt(0) also waits for the panel prefetch; v_readlane of spilled SGPRs), in a path that
                         // a fifth of all tiles take.
                         const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-                        (&g_wave_queue[0][0])[qidx + mb] = make_uint2(gm | ((32u * (uint32_t)t) << 16), ((jsp + 32u * p) << 1) + qcol);
+                        g_wave_queue[qidx + mb] = make_uint2(gm | ((32u * (uint32_t)t) << 16), ((jsp + 32u * p) << 1) + qcol);
                     }
                     qidx += nl;
                 };
@@ -844,39 +876,40 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
     // the same four numbers -- whether to settle the queues now (drain_queues_wg).
     auto publish = [&]() {
         if constexpr (QUEUE) {
-            if (lane == 0u) g_wave_qn[wave] = qidx - wave * kQWaveCap;
+            if (lane == 0u) g_wave_qn[wave] = qidx - wave * QCAP;
         }
     };
     auto settle = [&](const bool final, uint4* free_panel) {
         if constexpr (QUEUE) {
-            const uint4 q4 = *reinterpret_cast<const uint4*>(g_wave_qn);
-            const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.x), n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.y);
-            const uint32_t n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.z), n3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q4.w);
-            const uint32_t sum = n0 + n1 + n2 + n3, mx = max(max(n0, n1), max(n2, n3));
-            if (final ? sum != 0u : (sum >= kQDrainAt || mx > kQWaveCap - kQSuperMax)) {
+            const QCounts qc = load_qcounts(WAVES);
+            const uint32_t sum = qc.pre[kQMaxWaves];
+            uint32_t mx = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) mx = max(mx, qc.pre[w + 1] - qc.pre[w]);
+            if (final ? sum != 0u : (sum >= kQDrainAt || mx > QCAP - QSUPERMAX)) {
 #if !(defined(HVD_K2_QABL) && HVD_K2_QABL == 3)  // 3 = pushed entries are dropped instead of settled
-                const uint32_t left = drain_filter_wg(ctx, n0, n1, n2, n3, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
-                if (__builtin_expect(__any(left != 0u), 0)) settle_marked_wg(ctx, n0, n1, n2, n3, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                const uint32_t left = drain_filter_wg(ctx, (uint32_t)WAVES | (QCAP << 8), row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                if (__builtin_expect(__any(left != 0u), 0)) settle_marked_wg(ctx, (uint32_t)WAVES | (QCAP << 8), row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
 #endif
-                qidx = wave * kQWaveCap;
+                qidx = wave * QCAP;
                 __syncthreads();  // nobody pushes (or publishes) again before everybody has read the queues
             }
         }
     };
 
-    stage_super_panel(img + (size_t)j0 * 8u, lds0, wave, lane);
+    stage_super_panel<WAVES>(img + (size_t)j0 * 8u, lds0, wave, lane);
     __syncthreads();
 
     for (uint32_t sp = 0; sp < nsp; sp += 2) {
         const uint32_t jsp = j0 + sp * kSuper;
         // lds1 was last read in iteration sp-1, which every wave left through a barrier
-        if (sp + 1u < nsp) stage_super_panel(img + (size_t)(jsp + kSuper) * 8u, lds1, wave, lane);
+        if (sp + 1u < nsp) stage_super_panel<WAVES>(img + (size_t)(jsp + kSuper) * 8u, lds1, wave, lane);
         process(lds0, jsp);
         publish();
         __syncthreads();  // (drains the in-flight global->LDS loads with vmcnt(0) first)
         if (sp + 1u >= nsp) break;
         settle(false, lds0);  // (lds0 has just been used up and is not refilled before the settlement is over)
-        if (sp + 2u < nsp) stage_super_panel(img + (size_t)(jsp + 2u * kSuper) * 8u, lds0, wave, lane);
+        if (sp + 2u < nsp) stage_super_panel<WAVES>(img + (size_t)(jsp + 2u * kSuper) * 8u, lds0, wave, lane);
         process(lds1, jsp + kSuper);
         publish();
         __syncthreads();
@@ -884,7 +917,7 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
     }
     settle(true, lds0);  // (nothing is in flight any more: both buffers are free)
     // every path leaves the loop through a barrier: all hits of this workgroup are in LDS now
-    flush_pairs_wg(ctx, wave * 64u + lane);
+    flush_pairs_wg(ctx, wave * 64u + lane, NT);
 }
 
 // Probe for the data-dependent choice of the kernel form: over a strided sample of the two images (up to 4096 rows
@@ -1012,7 +1045,7 @@ static uint32_t pick_col_chunk_m(uint32_t n_pad, uint32_t rows_per_wg) {
 }
 
 struct MfmaForm {
-    int tiles, nbr, s1;
+    int tiles, nbr, s1, waves = 4;
 };
 // variants: 8 = 256 bits at once; 9 = 128-bit first stage, survivors fetch their other half (default for uniform
 // data); 10 / 11 = the same with 4 tiles per wave; 12 = 128-bit first stage, second stage out of registers (4 tiles);
@@ -1026,6 +1059,7 @@ static bool mfma_form(int variant, MfmaForm* f) {
         case 12: *f = {4, 4, 2}; return true;
         case 14: *f = {8, 4, 2}; return true;  // experiment: register form with 8 tiles per wave (2 waves/SIMD)
         case 15: *f = {8, 2, 2}; return true;  // pair-queue form: survivors settled pair by pair on the VALU
+        case 16: *f = {4, 2, 2, 8}; return true;  // the same with 8 waves of 4 tiles per workgroup: 4 resident waves per SIMD
         default: return false;
     }
 }
@@ -1033,7 +1067,7 @@ static bool mfma_form(int variant, MfmaForm* f) {
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk) {
     MfmaForm f;
     if (!mfma_form(variant, &f)) return false;
-    *rows_per_block = 128u * (uint32_t)f.tiles;
+    *rows_per_block = 32u * (uint32_t)f.tiles * (uint32_t)f.waves;
     *col_chunk = pick_col_chunk_m(fp4_rows_padded(n), *rows_per_block);
     return true;
 }
@@ -1065,11 +1099,11 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
 }
 
 // One launch of one form. rect: rows = the nq hashes of d_img_q, columns = the a.n hashes of d_img.
-template <int T, int NBR, int S1, bool QUEUE = false>
+template <int T, int NBR, int S1, bool QUEUE = false, int WAVES = 4>
 static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q, uint32_t nq,
                               const int32_t* d_group_t, const uint32_t* d_select, uint32_t select_id, hipStream_t s) {
     const uint32_t n_pad = fp4_rows_padded(a.n);
-    constexpr uint32_t ROWS = 128u * T;
+    constexpr uint32_t ROWS = 32u * T * WAVES;
     const uint32_t nrows = rect ? nq : a.n;
     const uint64_t n_rb = (nrows + ROWS - 1) / ROWS;
     uint64_t chunk;
@@ -1090,11 +1124,11 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
     HitCtx* ctx = reinterpret_cast<HitCtx*>(buf + 16);
     hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1, rect ? d_img_q : d_img, d_img));
     if (rect)
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE>), grid, dim3(256), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE, WAVES>), grid, dim3(64 * WAVES), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
                            select_id);
     else
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE>), grid, dim3(256), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE, WAVES>), grid, dim3(64 * WAVES), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)nullptr, fp4_scale2(), ctx, d_select,
                            select_id);
     return hipGetLastError();
@@ -1110,6 +1144,7 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
         case 12: return launch_form<4, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 12u, s);
         case 14: return launch_form<8, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 14u, s);
         case 15: return launch_form<8, 2, 2, true>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 15u, s);
+        case 16: return launch_form<4, 2, 2, true, 8>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 16u, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1181,10 +1216,10 @@ static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rec
 }
 
 static int effective_variant(int variant, uint32_t max_dist, uint32_t n) {
-    if (variant == 15 && fp4_rows_padded(n) >= (1u << 31)) variant = 12;  // the pair queue keeps (column << 1 | half) in 32 bits
+    if ((variant == 15 || variant == 16) && fp4_rows_padded(n) >= (1u << 31)) variant = 12;  // the pair queue keeps (column << 1 | half) in 32 bits
     // the 128-bit first stage needs 128 - 2*max_dist > 0
     if (max_dist >= 64u) {
-        if (variant == 9 || variant == 13 || variant == 15) return 8;
+        if (variant == 9 || variant == 13 || variant == 15 || variant == 16) return 8;
         if (variant == 11 || variant == 12) return 10;
         if (variant == 14) return 8;
     }

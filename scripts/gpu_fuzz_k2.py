@@ -38,7 +38,7 @@ for seed in range(first, first + nseeds):
     group = (rng.integers(0, max(2, n // 7), n).astype(np.int32) if rng.random() < 0.4 else None)
     if group is not None:
         group.sort()
-    variant = int(rng.choice([8, 9, 10, 11, 12, 13, 13, 13, 14, 15, 15, 15]))
+    variant = int(rng.choice([8, 9, 10, 11, 12, 13, 13, 13, 14, 15, 15, 16, 16, 16]))
     want = O.allpairs(db, md, group=group, cap=1 << 22, num_threads=8)
     d_db = L.DeviceBuffer.from_array(db)
     d_img = M.expand_fp4(d_db.ptr, n)

@@ -69,7 +69,7 @@ def test_k2_probe_picks_the_pair_queue_on_frame_hashes(gpu, hvd, oracle, frame_l
     got = _run(gpu, hvd, frames, 13, group=video, cap=len(want) + 16)
     assert _auto(gpu, b"mfma_auto_form") == 15 and _auto(gpu, b"mfma_probe_survivors") > 100
     assert np.array_equal(got, want)
-    for v in (15, 12, 9):
+    for v in (15, 16, 12, 9):
         assert np.array_equal(_run(gpu, hvd, frames, v, group=video, cap=len(want) + 16), want), v
     assert np.array_equal(_run(gpu, hvd, frames, 15, cap=1 << 20), oracle.allpairs(frames, 31, num_threads=8, cap=1 << 22))
 
@@ -81,7 +81,8 @@ def test_k2_pair_queue_settles_from_the_images_when_there_are_no_packed_hashes(g
     lib = gpu.load()
     gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 0))
     try:
-        assert np.array_equal(_run(gpu, hvd, sub, 15, group=video[:30000], cap=len(want) + 16), want)
+        for v in (15, 16):
+            assert np.array_equal(_run(gpu, hvd, sub, v, group=video[:30000], cap=len(want) + 16), want), v
     finally:
         gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 1))
 
@@ -151,7 +152,7 @@ def test_k2_pair_queue_overflowing_tiles_take_the_tile_route(gpu, hvd, oracle):
     db[4000, 20] ^= 0x3
     want = oracle.allpairs(db, 31, num_threads=8, cap=1 << 22)
     assert len(want) >= 2
-    for v in (15, 12):
+    for v in (15, 16, 12):
         assert np.array_equal(_run(gpu, hvd, db, v, cap=len(want) + 16), want), v
 
 
