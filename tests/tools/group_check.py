@@ -111,6 +111,22 @@ L.check(lib.hvd_debug_set(b"vmatch_fail_rank", 0))
 L.set_context(0)
 assert np.array_equal(hvd_amd.match_videos(frames, offsets, 31), wantv)
 
+# ---- the drop-in surfaces above the entry points: SQLite adapter and the VpTreeManager facade on a library large enough to
+#      be sharded (>= 4096 frames), against the oracle standing in for the matcher ------------------------------------------
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_sqlite_adapter import OracleMatcher, build_db  # noqa: E402
+from test_vptree_facade import reference_search_loop, unordered  # noqa: E402
+
+conn_g, blobs_g = build_db(hvd_amd, n_videos=420, seed=83)
+conn_o, blobs_o = build_db(hvd_amd, n_videos=420, seed=83)
+assert blobs_g == blobs_o and sum(len(b) for b in blobs_g) // 32 >= 4096
+pairs_gpu, cnt_gpu = hvd_amd.sqlite_adapter.find_potential_duplicates(conn_g, 50.0)
+pairs_orc, cnt_orc = hvd_amd.sqlite_adapter.find_potential_duplicates(conn_o, 50.0, matcher=OracleMatcher(O))
+assert pairs_gpu == pairs_orc and cnt_gpu == cnt_orc and len(pairs_gpu) >= 5
+conn_t, _ = build_db(hvd_amd, n_videos=420, seed=83)
+directed, _ = reference_search_loop(conn_t, hvd_amd.vptree.VpTreeManager(conn_t), 50.0, hvd_amd)
+assert unordered(conn_t, directed) == {(a, b) for a, b, _ in pairs_orc}
+
 # ---- a streaming hasher lives on the context it was created on, whoever calls it -------------------------------------------
 L.set_context(W - 1)
 vh = hvd_amd.VideoHasher(1, 64, 64, 0)
