@@ -778,22 +778,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
                         }
                     }
 #endif
-                    if (nl > kQTileLanes) {
-                        tmarks |= 1u << (TILES - 1 - t);
-                        return;
-                    }
-                    if (gm != 0u) {
+                    // no scalar branch in here: a dense tile only masks the push off and sets its mark
+                    const bool dense = nl > kQTileLanes;
+                    tmarks |= dense ? 1u << (TILES - 1 - t) : 0u;
+                    if (gm != 0u && !dense) {
                         // Nothing in an entry but the mask is the lane's own business or the wave's: the tile is a literal, the
                         // wave follows from the queue the entry sits in, the lane's half h rides in bit 0 of y next to the
                         // column, whose lane-constant part is a register the loop holds anyway -- and the queue's index is the
                         // fill level itself (qidx; the array stays NAMED in the store: through a bare LDS address the compiler
-                        // cannot tell it from the panel buffers and waits for the prefetch in flight, vmcnt(0), first). Every per-lane or per-wave constant tried here ended up spilled (a scratch
+                        // cannot tell it from the panel buffers and waits for the prefetch in flight, vmcnt(0), first).
+                        // Every per-lane or per-wave constant tried here ended up spilled (a scratch
                         // reload whose vmcnt(0) also waits for the panel prefetch; v_readlane of spilled SGPRs), in a path that
                         // a fifth of all tiles take.
                         const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
                         g_wave_queue[qidx + mb] = make_uint2(gm | ((32u * (uint32_t)t) << 16), ((jsp + 32u * p) << 1) + qcol);
                     }
-                    qidx += nl;
+                    qidx += dense ? 0u : nl;
                 };
                 static_assert(kSign, "the pair-queue form reads sign bits (HVD_K2_SIGN=1)");
                 auto hit = [&](const Or16Groups& o) { return __any(o.all < 0); };
