@@ -586,7 +586,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             exec_cmp5 = float(kept5) * (float(kept5) - 1.0) / 2.0 / world
             flop5 = exec_cmp5 / 1024.0 * 2.0 * 131072.0
             search5 = {"ms": round(search5_ms, 3), "ms_sd": round(search5_sd, 3), "form": int(fv5.value),
-                       "form_name": {9: "fetch", 12: "register cascade", 15: "pair queue"}.get(int(fv5.value), "?"),
+                       "form_name": {9: "fetch", 12: "register cascade", 15: "pair queue (group masks)", 18: "pair queue (panel marks)"}.get(int(fv5.value), "?"),
                        "frame_comparisons_per_s": sig(fcmp5 / (search5_ms * 1e-3)),
                        "executed_comparisons_per_s": sig(exec_cmp5 * world / (search5_ms * 1e-3)),
                        "note": "HIP-event time of the whole hvd_dev_vpdq_match_videos call on the library stream (packed hashes, "
@@ -596,7 +596,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                                     "frac": round(flop5 / (search5_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS, 4),
                                     "flop_per_launch": flop5,
                                     "basis": "first-stage MFMAs only (2 per 1024 executed comparisons, per rank) over the time of the "
-                                             "whole call; counters: profiles/r04_pmc_k2_structured15.txt", "traffic": None}}
+                                             "whole call; counters: profiles/r04_pmc_k2_structured18.txt", "traffic": None}}
             extras["cfg5"] = {"workload": f"BASELINE configs[4]: {V} synthetic videos x {F} distinct 64x64 frames generated in HBM -> PDQ hash -> "
                                 "quality filter + CSR on the GPU -> FP4 image -> all video pairs with the vPDQ counters reduced on "
                                 f"the GPU -> pair predicate (threshold 50); {world} GPU(s): frames hashed in disjoint video ranges, "
@@ -663,7 +663,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                          "because tiles re-use operands from registers/LDS"}
     if variant >= 8:
         # executed matrix work: 2 (128-bit first stage) or 4 MFMAs of 2*32*32*64 flop per 1024 comparisons
-        flop_per_cmp = 256.0 if form in (9, 11, 12, 15) else 512.0
+        flop_per_cmp = 256.0 if form in (9, 11, 12, 15, 18) else 512.0
         tfl = cmp_per_launch * flop_per_cmp / (kernel_avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": f"k_allpairs_mfma(variant={variant}" + (f" -> form {form} chosen by the probe)" if variant == 13 else ")"),
                     "achieved": round(tfl, 1),
@@ -764,7 +764,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         # every exact form next to the default, for transparency (same DB, same launch shape)
         for v, name in ((0, "popcount_full_16op"), (1, "popcount_prefilter128"), (8, "mfma_fp4_full_256"),
                         (9, "mfma_fp4_stage128_fetch"), (12, "mfma_fp4_stage128_registers"),
-                        (15, "mfma_fp4_stage128_pair_queue")):
+                        (15, "mfma_fp4_stage128_pair_queue"), (18, "mfma_fp4_stage128_panel_mark_queue")):
             mu, sd, _ = time_variant(v, reps=3)
             extra[name] = {"kernel_ms": round(mu, 3), "kernel_ms_sd": round(sd, 3), "comparisons_per_s": sig(total_cmp / (mu * 1e-3))}
         out["kernel_variants"] = extra

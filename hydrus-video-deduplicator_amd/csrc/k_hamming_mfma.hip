@@ -502,7 +502,7 @@ __device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx,
     const uint32_t geom = geom_v, row0 = row0_v, ohw = other_half_v;
     const HitCtx* cc = ctx;
 #endif
-    const uint32_t waves = geom & 15u, qcap = geom >> 8, nthreads = 64u * waves;  // waves | entries per wave << 8
+    const uint32_t waves = geom & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;  // waves | tiles << 4 | entries per wave << 8
     const QCounts qc = load_qcounts(waves);
     const uint32_t total = qc.pre[kQMaxWaves];
     const uint4* __restrict__ db_q = cc->db_q;
@@ -576,7 +576,7 @@ __device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, ui
     const uint32_t geom = geom_v, row0 = row0_v, ohw = other_half_v;
 #endif
     const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
-    const uint32_t waves = geom & 15u, qcap = geom >> 8, nthreads = 64u * waves;
+    const uint32_t waves = geom & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;
     const QCounts qc = load_qcounts(waves);
     const HitCtx c = load_ctx(ctx);
     const uint32_t total = qc.pre[kQMaxWaves];
@@ -610,6 +610,190 @@ __device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, ui
             }
         }
     }
+}
+
+// ---- panel-mark queue (QUEUE = 2) -------------------------------------------------------------------------------------
+// What the group-mask queue above still pays in the panel loop -- a taken branch and ~11 VALU instructions per SURVIVING TILE,
+// a fifth of all tiles of a frame-hash library, executed by a whole wave for the one lane that holds the survivor -- moves
+// behind the barrier as well: the panel loop is the fetch form's (one v_alignbit per tile shifts the tile's verdict into a
+// per-lane mask), and per PANEL the lanes whose mask is not empty push it, with their column, branch-free (a ballot, two
+// counts, one predicated ds_write_b64). Which of the lane's 16 rows of a marked tile it was is not recorded at all: the
+// settlement filters all 16 against the column on the 128 bits the first stage did not see -- 16 LDS reads and ~150 VALU
+// operations of ONE lane per entry instead of six wave-wide instructions per surviving tile in the loop.
+// entry: x = the lane's tile marks (bit TILES-1-t <-> tile t); y as above. The filter writes back the marks of the tiles in
+// which some row passed (x = 0: nothing left), settle_marked_panel_wg walks those again and settles every passing row.
+constexpr uint32_t kQPanelLanes = 16;  // a panel in which more lanes than this hold a survivor takes the tile route
+
+// A mark stands for 16 / Q accumulator registers of one tile (Q = 1, 2, 4 marks per tile: the OR tree is cut into as many
+// parts, one v_alignbit each); registers 4c .. 4c+3 are four CONSECUTIVE rows, ibrel + 8c + 0..3 (qrow_of). Mark number
+// idx = t * Q + q sits in bit (TILES * Q - 1 - idx) of a lane's mask.
+#ifndef HVD_K2_QROT
+#define HVD_K2_QROT 1
+#endif
+#ifndef HVD_K2_QFULL
+#define HVD_K2_QFULL 1
+#endif
+#ifndef HVD_K2_QSPLIT
+#define HVD_K2_QSPLIT 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// Does any of four consecutive rows pass? Every lane's four rows start at a multiple of 64 bytes, so a ds_read_b128 that
+// takes the r-th row of every lane finds all of them in 4 of the 16 groups of four banks: the lanes walk their rows in an
+// order rotated by the lane number instead (which row passed is not asked here).
+__device__ __forceinline__ uint32_t filter_rows4(const __attribute__((address_space(3))) uint4* rows, uint32_t rot,
+                                                 const uint4& col, uint32_t max_dist) {
+    uint32_t pass = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 4u; ++r) pass |= sign_popc(rows[(r + (HVD_K2_QROT ? rot : 0u)) & 3u], col, 0u) <= max_dist ? 1u << r : 0u;
+    return pass;
+}
+#endif
+// geom: waves | tiles << 4 | entries per wave << 8 | marks per tile << 20
+__device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict__ ctx, uint32_t geom_v, uint32_t row0_v,
+                                                       uint32_t other_half_v, uint32_t tid, uint4* rows_generic) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto* rows_lds = (__attribute__((address_space(3))) uint4*)rows_generic;
+    const uint32_t geom = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom_v);
+    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
+    const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
+    const auto* cc = (const __attribute__((address_space(4))) HitCtx*)uniform_u64((unsigned long long)ctx);
+    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = geom >> 20, nthreads = 64u * waves;
+    const uint32_t qshift = qg >> 1, chunks = 4u >> qshift, top = tiles * qg - 1u;  // qg = 1, 2, 4 -> shift 0, 1, 2; 4-row chunks per mark
+    const QCounts qc = load_qcounts(waves);
+    const uint32_t total = qc.pre[kQMaxWaves];
+    const uint4* __restrict__ db_q = cc->db_q;
+    const uint4* __restrict__ db_t = cc->db_t;
+    const uint32_t max_dist = cc->max_dist;
+    if (db_t == nullptr) return 1u;  // launch-uniform: no packed hashes, every mark stays to do
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 6  // timing-only ablation: the call and nothing else
+    return 0u;
+#endif
+    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;
+    const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;
+    constexpr int E = 3;
+    uint32_t left = 0;
+    bool staged = false;
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < total; k0 += nthreads * E) {
+        uint32_t ex[E], lanerel[E];
+        uint4 col[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const uint32_t k = k0 + tid + nthreads * (uint32_t)u;
+            ex[u] = 0u;
+            lanerel[u] = 0u;
+            col[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (k < total) {
+                uint32_t w;
+                const uint2 e = *queue_entry(k, qc, qcap, &w);
+                ex[u] = e.x;
+                lanerel[u] = 4u * (e.y & 1u) + wrows * w;  // the lane's first row, relative to row0
+                col[u] = db_t[(size_t)(e.y >> 1) * 2u + oh];
+            }
+        }
+        // the workgroup's own rows (coalesced) are requested BEHIND the first round's column gathers, so that the two memory
+        // round trips of a settlement run side by side
+        if (!staged) {
+#pragma unroll
+            for (uint32_t r = tid; r < kSuper * 8u; r += nthreads) rows_lds[r] = db_q[(size_t)min(row0 + r, last) * 2u + oh];
+            __syncthreads();
+            staged = true;
+        }
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 9  // timing-only ablation: entries, columns and rows are fetched, nothing is filtered
+        asm volatile("" ::"v"(col[0].x ^ col[1].y ^ col[2].z ^ ex[0] ^ lanerel[1]));
+        continue;
+#endif
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const uint32_t k = k0 + tid + nthreads * (uint32_t)u;
+            if (k >= total) continue;
+            uint32_t m = ex[u], kept = 0;
+#pragma unroll 1
+            while (m != 0u) {
+                const uint32_t bit = 31u - (uint32_t)__clz((int)m);
+                m &= ~(1u << bit);
+                const uint32_t idx = top - bit, t = idx >> qshift, q = idx & (qg - 1u);
+                const uint32_t ib = lanerel[u] + 32u * t + 8u * chunks * q;
+                uint32_t pass = 0;
+#pragma unroll 1
+                for (uint32_t c = 0; c < chunks; ++c) {
+                    uint32_t p4 = filter_rows4(rows_lds + ib + 8u * c, tid, col[u], max_dist);
+#if HVD_K2_QFULL
+                    // A row that passes here by chance (2.3e-4 of them: one or two per settlement) would send the whole
+                    // workgroup through settle_marked_panel_wg -- another walk over the queues and another memory round trip
+                    // with everybody waiting. The lane that found it looks at the first stage's half as well, on the spot;
+                    // what it keeps is a hit.
+                    if (__builtin_expect(p4 != 0u, 0)) {
+                        uint32_t w2;
+                        const uint32_t j = queue_entry(k, qc, qcap, &w2)->y >> 1;
+                        const uint4 cf = db_t[(size_t)j * 2u + (oh ^ 1u)];
+                        uint32_t hit = 0;
+#pragma unroll 1
+                        while (p4 != 0u) {
+                            const uint32_t r = (uint32_t)__ffs((int)p4) - 1u;
+                            p4 &= p4 - 1u;
+                            const uint32_t rowrel = ib + 8u * c + ((r + (HVD_K2_QROT ? tid : 0u)) & 3u);
+                            const uint4 rf = db_q[(size_t)min(row0 + rowrel, last) * 2u + (oh ^ 1u)];
+                            if (sign_popc(rf, cf, sign_popc(rows_lds[rowrel], col[u], 0u)) <= max_dist) hit = 1u;
+                        }
+                        p4 = hit;
+                    }
+#endif
+                    pass |= p4;
+                }
+                if (pass != 0u) kept |= 1u << bit;
+            }
+            left |= kept;
+            uint32_t w_;
+            queue_entry(k, qc, qcap, &w_)->x = kept;
+        }
+    }
+    return left;
+#else
+    (void)ctx; (void)geom_v; (void)row0_v; (void)other_half_v; (void)tid; (void)rows_generic;
+    return 0u;
+#endif
+}
+
+__device__ __noinline__ void settle_marked_panel_wg(const HitCtx* __restrict__ ctx, uint32_t geom_v, uint32_t row0_v,
+                                                    uint32_t other_half_v, uint32_t tid, const uint4* rows_generic) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto* rows_lds = (const __attribute__((address_space(3))) uint4*)rows_generic;
+    const uint32_t geom = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom_v);
+    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
+    const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
+    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;
+    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = geom >> 20, nthreads = 64u * waves;
+    const uint32_t qshift = qg >> 1, nrows = 16u >> qshift, top = tiles * qg - 1u;
+    const QCounts qc = load_qcounts(waves);
+    const HitCtx c = load_ctx(ctx);
+    const uint32_t total = qc.pre[kQMaxWaves];
+    const bool packed = c.db_t != nullptr;
+#pragma unroll 1
+    for (uint32_t k = tid; k < total; k += nthreads) {
+        uint32_t w;
+        const uint2 e = *queue_entry(k, qc, qcap, &w);
+        uint32_t m = e.x;
+        if (m == 0u) continue;
+        const uint32_t lanerel = 4u * (e.y & 1u) + wrows * w, j = e.y >> 1;
+        const uint4 col = packed ? c.db_t[(size_t)j * 2u + oh] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 1
+        while (m != 0u) {
+            const uint32_t bit = 31u - (uint32_t)__clz((int)m);
+            m &= ~(1u << bit);
+            const uint32_t idx = top - bit, t = idx >> qshift, q = idx & (qg - 1u);
+            const uint32_t ibrel = lanerel + 32u * t, r0 = nrows * q;
+#pragma unroll 1
+            for (uint32_t r = r0; r < r0 + nrows; ++r) {
+                const uint32_t rr = qrow_of(ibrel, r);
+                if (packed && sign_popc(rows_lds[rr], col, 0u) > c.max_dist) continue;
+                settle_pair(c, row0 + rr, j);
+            }
+        }
+    }
+#else
+    (void)ctx; (void)geom_v; (void)row0_v; (void)other_half_v; (void)tid; (void)rows_generic;
+#endif
 }
 
 // Stage one 16 KB super-panel (128 hashes x 128 B, contiguous in the image) into LDS with
@@ -647,7 +831,7 @@ __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src,
 //   WAVES  waves per workgroup: 4, or 8 (QUEUE with 4 tiles per wave: the same 1024 rows per workgroup and the same panels
 //          shared by twice as many, lighter waves -- <= 128 VGPRs = FOUR resident waves per SIMD. The pair-queue form lives on
 //          resident waves: 1 / 2 / 3 per SIMD take 40.6 / 23.0 / 18.2 ms on frame hashes, profiles/r04_k2_queue_ablation.txt).
-template <int TILES, int NBR, int S1, bool RECT, bool QUEUE = false, int WAVES = 4>
+template <int TILES, int NBR, int S1, bool RECT, int QUEUE = 0, int WAVES = 4>
 // (the 4-tile register form is held to 3 waves per SIMD = 168 VGPRs: with the pre-read fragment it would take 170)
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
                                                           uint32_t max_dist, uint32_t col_chunk, uint32_t rank,
@@ -660,7 +844,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
     static_assert(WAVES == 4 || (WAVES == 8 && QUEUE), "8-wave workgroups exist for the pair-queue form");
     constexpr uint32_t WROWS = 32u * TILES, ROWS = (uint32_t)WAVES * WROWS, NT = 64u * WAVES;
     // QUEUE: entries per wave, and the most one wave can add between two barriers
-    constexpr uint32_t QCAP = kQEntries / WAVES, QSUPERMAX = (kSuper / 32) * TILES * kQTileLanes;
+    constexpr int QG = QUEUE == 2 ? 1 : QUEUE == 3 ? 2 : QUEUE == 4 ? 4 : 0;  // panel-mark queue: marks per tile
+    static_assert(TILES * QG <= 32, "a lane's marks are one word");
+    constexpr uint32_t QCAP = kQEntries / WAVES, QSUPERMAX = (kSuper / 32) * (QUEUE >= 2 ? (HVD_K2_QSPLIT ? 2u : 1u) * kQPanelLanes : TILES * kQTileLanes);
     static_assert(!QUEUE || QCAP >= QSUPERMAX + 64, "a wave's queue must take a super-panel's worth on top of a carry-over");
     __shared__ uint4 lds0[kSuper * 8], lds1[kSuper * 8];
 
@@ -749,7 +935,63 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
             if constexpr (NBR == 4 && S1 == 2 && kCascade) b192 = as_v4i(base[(4u + h) ^ sw]);
 
             // two accumulator sets: the MFMAs of tile t+1 are issued before the max tree of tile t
-            if constexpr (QUEUE) {
+            if constexpr (QUEUE >= 2) {
+                // the fetch form's loop; what it marks is pushed once per panel, with no branch (panel-mark queue, above)
+                uint32_t marks = 0;  // bit (TILES * QG - 1 - (t * QG + q)) <-> registers 16 / QG * q ... of tile t
+                auto part_mark = [&](uint32_t mk, const v16f& acc) -> uint32_t {
+                    if constexpr (QG == 1) {
+                        return __builtin_amdgcn_alignbit(mk, (uint32_t)or16_bits(acc), 31);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < QG; ++q) {
+                            int x = 0;
+#pragma unroll
+                            for (int r = 0; r < 16 / QG; ++r) x |= __float_as_int(acc[16 / QG * q + r]);
+                            mk = __builtin_amdgcn_alignbit(mk, (uint32_t)x, 31);
+                        }
+                        return mk;
+                    }
+                };
+                v16f cur = tile_dot<0, S1>(a[0], b, zero);
+#pragma unroll
+                for (int t = 1; t < TILES; ++t) {
+                    const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
+                    marks = part_mark(marks, cur);
+                    cur = nxt;
+                }
+                marks = part_mark(marks, cur);
+                const unsigned long long act = __ballot(marks != 0u);
+                const uint32_t nl = (uint32_t)__builtin_popcount((uint32_t)act) + (uint32_t)__builtin_popcount((uint32_t)(act >> 32));
+                const bool dense = nl > kQPanelLanes;
+#if defined(HVD_K2_QABL) && (HVD_K2_QABL == 8 || HVD_K2_QABL == 10)  // timing-only ablation (wrong results): survivors are counted, nothing is pushed
+                asm volatile("" ::"s"(nl));
+#else
+                // One mark per entry: the settlement's lanes take an entry each and walk its marks, so a wave is as slow as its
+                // lane with the most -- and 6 % of the lanes that push hold two (two tiles of one column): 98 % of the waves
+                // would walk twice for them. A lane's lowest mark goes into one entry, whatever else it holds into a second.
+                const uint32_t low = HVD_K2_QSPLIT ? marks & (0u - marks) : marks, rest = marks ^ low;
+                const unsigned long long act2 = __ballot(rest != 0u);
+                const uint32_t nl2 = (uint32_t)__builtin_popcount((uint32_t)act2) + (uint32_t)__builtin_popcount((uint32_t)(act2 >> 32));
+                if (marks != 0u && !dense) {
+                    const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                    g_wave_queue[qidx + mb] = make_uint2(low, ((jsp + 32u * p) << 1) + qcol);
+                }
+                if (rest != 0u && !dense) {
+                    const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act2, 0u));
+                    g_wave_queue[qidx + nl + mb] = make_uint2(rest, ((jsp + 32u * p) << 1) + qcol);
+                }
+                qidx += dense ? 0u : nl + nl2;
+#endif
+                if (__builtin_expect(dense, 0)) {
+                    uint32_t tm = marks;  // one bit per tile for the tile route
+                    if constexpr (QG > 1) {
+                        tm = 0;
+#pragma unroll
+                        for (int t = 0; t < TILES; ++t) tm |= ((marks >> (QG * (TILES - 1 - t))) & ((1u << QG) - 1u)) != 0u ? 1u << (TILES - 1 - t) : 0u;
+                    }
+                    panel_survivors<TILES>(tm, imgq, panel, wrow0, jsp + 32u * p, lane, ctx);
+                }
+            } else if constexpr (QUEUE) {
                 // Each tile is judged while its accumulators are live; a surviving tile hands its few surviving PAIRS to the
                 // wave's queue (or, when there are many, its index to the tile route) and the matrix pipe moves on.
                 uint32_t tmarks = 0;  // wave-uniform: bit (TILES-1-t) <-> tile t takes the tile route
@@ -874,22 +1116,41 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
 
     // QUEUE: every wave publishes its fill level in front of a super-panel barrier; behind it the workgroup decides -- on
     // the same four numbers -- whether to settle the queues now (drain_queues_wg).
+    const uint32_t drain_at = kQDrainAt;
     auto publish = [&]() {
         if constexpr (QUEUE) {
             if (lane == 0u) g_wave_qn[wave] = qidx - wave * QCAP;
         }
     };
     auto settle = [&](const bool final, uint4* free_panel) {
+#if defined(HVD_K2_QABL) && HVD_K2_QABL == 10  // timing-only ablation: (with nothing pushed) no look at the fill levels either
+        return;
+#endif
         if constexpr (QUEUE) {
             const QCounts qc = load_qcounts(WAVES);
             const uint32_t sum = qc.pre[kQMaxWaves];
             uint32_t mx = 0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) mx = max(mx, qc.pre[w + 1] - qc.pre[w]);
-            if (final ? sum != 0u : (sum >= kQDrainAt || mx > QCAP - QSUPERMAX)) {
+            if (final ? sum != 0u : (sum >= drain_at || mx > QCAP - QSUPERMAX)) {
+#ifdef HVD_K2_QSTATS
+                if (wave == 0u && lane == 0u) {
+                    const HitCtx cs = load_ctx(ctx);
+                    atomicAdd(&cs.qstats[4], 1ull);
+                    atomicAdd(&cs.qstats[5], (unsigned long long)sum);
+                    if (final) atomicAdd(&cs.qstats[6], 1ull);
+                    else if (sum < kQDrainAt) atomicAdd(&cs.qstats[7], 1ull);
+                }
+#endif
 #if !(defined(HVD_K2_QABL) && HVD_K2_QABL == 3)  // 3 = pushed entries are dropped instead of settled
-                const uint32_t left = drain_filter_wg(ctx, (uint32_t)WAVES | (QCAP << 8), row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
-                if (__builtin_expect(__any(left != 0u), 0)) settle_marked_wg(ctx, (uint32_t)WAVES | (QCAP << 8), row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                constexpr uint32_t GEOM = (uint32_t)WAVES | ((uint32_t)TILES << 4) | (QCAP << 8) | ((uint32_t)QG << 20);
+                if constexpr (QUEUE >= 2) {
+                    const uint32_t left = drain_filter_panel_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                    if (__builtin_expect(__any(left != 0u), 0)) settle_marked_panel_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                } else {
+                    const uint32_t left = drain_filter_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                    if (__builtin_expect(__any(left != 0u), 0)) settle_marked_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                }
 #endif
                 qidx = wave * QCAP;
                 __syncthreads();  // nobody pushes (or publishes) again before everybody has read the queues
@@ -1020,7 +1281,7 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
 // and the survivor density (per 1024-pair tile, as the probe estimates it) up to which it is preferred over the register form
 uint32_t g_mfma_lds_pad = 0;  // occupancy experiments: unused dynamic LDS per workgroup (hvd_debug_set "mfma_lds_pad")
 uint32_t g_mfma_queue_packed = 1;  // 0: the pair queue settles from the FP4 images even when packed hashes are at hand (tests)
-uint32_t g_mfma_auto_mid = 15;
+uint32_t g_mfma_auto_mid = 18;
 uint32_t g_mfma_auto_mid_max_x100 = 130;  // (scripts/gpu_k2_rate_sweep.py: the queue form wins up to ~1 survivor per tile -- 0.77-0.82 of the
                                           // register form's time at 0.06-1.0 -- and loses from 2 on: 1.15x at 2, 2.4x at 4, the tile route)
 hipError_t launch_pack_fp4(const void* d_img, uint32_t n, void* d_db, hipStream_t s) {
@@ -1059,7 +1320,8 @@ static bool mfma_form(int variant, MfmaForm* f) {
         case 12: *f = {4, 4, 2}; return true;
         case 14: *f = {8, 4, 2}; return true;  // experiment: register form with 8 tiles per wave (2 waves/SIMD)
         case 15: *f = {8, 2, 2}; return true;  // pair-queue form: survivors settled pair by pair on the VALU
-        case 16: *f = {4, 2, 2, 8}; return true;  // the same with 8 waves of 4 tiles per workgroup: 4 resident waves per SIMD
+        case 16: *f = {4, 2, 2, 8}; return true;
+        case 17: case 18: case 19: *f = {8, 2, 2}; return true;  // panel-mark queue: the fetch form's loop, survivors pushed once per panel  // the same with 8 waves of 4 tiles per workgroup: 4 resident waves per SIMD
         default: return false;
     }
 }
@@ -1099,7 +1361,7 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
 }
 
 // One launch of one form. rect: rows = the nq hashes of d_img_q, columns = the a.n hashes of d_img.
-template <int T, int NBR, int S1, bool QUEUE = false, int WAVES = 4>
+template <int T, int NBR, int S1, int QUEUE = 0, int WAVES = 4>
 static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q, uint32_t nq,
                               const int32_t* d_group_t, const uint32_t* d_select, uint32_t select_id, hipStream_t s) {
     const uint32_t n_pad = fp4_rows_padded(a.n);
@@ -1143,8 +1405,11 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
         case 11: return launch_form<4, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 11u, s);
         case 12: return launch_form<4, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 12u, s);
         case 14: return launch_form<8, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 14u, s);
-        case 15: return launch_form<8, 2, 2, true>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 15u, s);
-        case 16: return launch_form<4, 2, 2, true, 8>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 16u, s);
+        case 15: return launch_form<8, 2, 2, 1>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 15u, s);
+        case 16: return launch_form<4, 2, 2, 1, 8>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 16u, s);
+        case 17: return launch_form<8, 2, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 17u, s);
+        case 18: return launch_form<8, 2, 2, 3>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 18u, s);
+        case 19: return launch_form<8, 2, 2, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 19u, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1216,10 +1481,10 @@ static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rec
 }
 
 static int effective_variant(int variant, uint32_t max_dist, uint32_t n) {
-    if ((variant == 15 || variant == 16) && fp4_rows_padded(n) >= (1u << 31)) variant = 12;  // the pair queue keeps (column << 1 | half) in 32 bits
+    if (variant >= 15 && variant <= 19 && fp4_rows_padded(n) >= (1u << 31)) variant = 12;  // the pair queue keeps (column << 1 | half) in 32 bits
     // the 128-bit first stage needs 128 - 2*max_dist > 0
     if (max_dist >= 64u) {
-        if (variant == 9 || variant == 13 || variant == 15 || variant == 16) return 8;
+        if (variant == 9 || variant == 13 || (variant >= 15 && variant <= 19)) return 8;
         if (variant == 11 || variant == 12) return 10;
         if (variant == 14) return 8;
     }

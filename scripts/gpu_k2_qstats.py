@@ -20,7 +20,7 @@ def stat(k):
     v = C.c_int(0); L.check(lib.hvd_debug_get(b"mfma_qstat%d" % k, C.byref(v))); return v.value
 for k in range(16): stat(k)
 d_cnt.zero()
-M.launch_allpairs(lib, libr.d_hashes.ptr, img.ptr, nk, libr.d_video.ptr, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, 15)
+M.launch_allpairs(lib, libr.d_hashes.ptr, img.ptr, nk, libr.d_video.ptr, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, int(sys.argv[1]) if len(sys.argv) > 1 else 15)
 L.check(lib.hvd_dev_sync())
 s = [stat(k) for k in range(16)]
 tiles = nk * (nk - 1) / 2 / 1024
@@ -28,3 +28,4 @@ print("kept", nk, "tiles %.3g" % tiles)
 print("surviving tiles", s[0], "= %.3f of tiles; survivors %d = %.3g of pairs; per surviving tile %.2f" % (s[0] / tiles, s[3], s[3] / (tiles * 1024), s[3] / max(s[0], 1)))
 print("tile route: lanes>16:", s[1], " heavy lane(>2):", s[2])
 print("survivors per surviving tile histogram (<=1,2,4,8,16,32,64,more):", s[8:16])
+print("settlements", s[4], "entries settled", s[5], "= %.1f each; at the end of a workgroup: %d; forced by one full queue: %d" % (s[5] / max(s[4], 1), s[6], s[7]))

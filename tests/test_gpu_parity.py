@@ -242,7 +242,7 @@ def _run_variant(gpu, hvd, db, variant, max_dist=31, group=None, cap=1 << 16):
     return hvd.multigpu.merge_pairs([d_pairs.to_array(gpu.PAIR_DTYPE, cnt)])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
     """Popcount (0..6) and FP4-MFMA (8..14) forms produce the identical pair list."""
     n = 20000
@@ -253,7 +253,7 @@ def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
     assert np.array_equal(_run_variant(gpu, hvd, db, variant, group=grp), oracle.allpairs(db, 31, group=grp, num_threads=8))
 
 
-@pytest.mark.parametrize("variant", [8, 9, 12, 13, 15, 16])
+@pytest.mark.parametrize("variant", [8, 9, 12, 13, 15, 16, 17, 18, 19])
 @pytest.mark.parametrize("max_dist", [0, 31, 63, 64, 127, 128, 256])
 def test_k2_mfma_threshold_routing(gpu, hvd, oracle, variant, max_dist):
     """dot >= 256-2*max_dist is the popcount predicate for every tolerance, including the ones
@@ -614,7 +614,7 @@ def test_randomized_differential_sweep(gpu, hvd, oracle, seed):
     # host entry (default kernel)
     assert np.array_equal(hvd.allpairs_hamming(db, md, group=grp), want)
     # every device variant
-    for variant in (0, 1, 3, 8, 9, 10, 11, 12, 13, 15, 16):
+    for variant in (0, 1, 3, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19):
         assert np.array_equal(_run_variant(gpu, hvd, db, variant, max_dist=md, group=grp, cap=max(len(want), 16)), want), variant
     # rank split of the default kernel
     world = int(rng.integers(2, 6))

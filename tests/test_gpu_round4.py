@@ -67,11 +67,13 @@ def test_k2_probe_picks_the_pair_queue_on_frame_hashes(gpu, hvd, oracle, frame_l
     want = oracle.allpairs(frames, 31, group=video, num_threads=8, cap=1 << 22)
     assert len(want) > 1000  # the planted copies
     got = _run(gpu, hvd, frames, 13, group=video, cap=len(want) + 16)
-    assert _auto(gpu, b"mfma_auto_form") == 15 and _auto(gpu, b"mfma_probe_survivors") > 100
+    assert _auto(gpu, b"mfma_auto_form") == 18 and _auto(gpu, b"mfma_probe_survivors") > 100
     assert np.array_equal(got, want)
-    for v in (15, 16, 12, 9):
+    for v in (15, 16, 17, 18, 19, 12, 9):
         assert np.array_equal(_run(gpu, hvd, frames, v, group=video, cap=len(want) + 16), want), v
-    assert np.array_equal(_run(gpu, hvd, frames, 15, cap=1 << 20), oracle.allpairs(frames, 31, num_threads=8, cap=1 << 22))
+    want_all = oracle.allpairs(frames, 31, num_threads=8, cap=1 << 22)
+    for v in (15, 18):
+        assert np.array_equal(_run(gpu, hvd, frames, v, cap=1 << 20), want_all), v
 
 
 def test_k2_pair_queue_settles_from_the_images_when_there_are_no_packed_hashes(gpu, hvd, oracle, frame_library):
@@ -81,7 +83,7 @@ def test_k2_pair_queue_settles_from_the_images_when_there_are_no_packed_hashes(g
     lib = gpu.load()
     gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 0))
     try:
-        for v in (15, 16):
+        for v in (15, 16, 17, 18, 19):
             assert np.array_equal(_run(gpu, hvd, sub, v, group=video[:30000], cap=len(want) + 16), want), v
     finally:
         gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 1))
@@ -90,7 +92,7 @@ def test_k2_pair_queue_settles_from_the_images_when_there_are_no_packed_hashes(g
 def test_k3_video_search_runs_through_the_pair_queue(gpu, hvd, oracle, frame_library):
     frames, offsets, video, libr = frame_library
     got = libr.match_videos(31)
-    assert _auto(gpu, b"mfma_auto_form") == 15
+    assert _auto(gpu, b"mfma_auto_form") == 18
     # oracle on a sub-library (every video pair of the first 400 videos + all planted copies are checked by recall below)
     sub_v = 400
     sub = oracle.match_videos(frames[: offsets[sub_v]], offsets[: sub_v + 1], 31)
@@ -104,6 +106,11 @@ def test_k3_video_search_runs_through_the_pair_queue(gpu, hvd, oracle, frame_lib
         assert _auto(gpu, b"mfma_auto_form") == 12
     finally:
         gpu.check(lib.hvd_debug_set(b"mfma_auto_mid", 15))
+    try:
+        assert np.array_equal(libr.match_videos(31), ref)  # (the group-mask queue, round 4's first queue form)
+        assert _auto(gpu, b"mfma_auto_form") == 15
+    finally:
+        gpu.check(lib.hvd_debug_set(b"mfma_auto_mid", 18))
     assert np.array_equal(got, ref) and len(got) > 20
     gpu.check(lib.hvd_debug_set(b"mfma_queue_packed", 0))
     try:
@@ -123,7 +130,7 @@ def test_k3_cross_search_runs_through_the_pair_queue(gpu, hvd, oracle, frame_lib
     t_v = 600
     got = hvd.search.match_videos_cross(q_frames, q_off, frames[: offsets[t_v]], offsets[: t_v + 1],
                                         ids_q=q_sel.astype(np.int32), ids_t=np.arange(t_v, dtype=np.int32))
-    assert _auto(gpu, b"mfma_auto_form") == 15
+    assert _auto(gpu, b"mfma_auto_form") == 18
     want = []
     for qi, v in enumerate(q_sel):
         a = frames[offsets[v]:offsets[v + 1]].tobytes()
@@ -152,7 +159,7 @@ def test_k2_pair_queue_overflowing_tiles_take_the_tile_route(gpu, hvd, oracle):
     db[4000, 20] ^= 0x3
     want = oracle.allpairs(db, 31, num_threads=8, cap=1 << 22)
     assert len(want) >= 2
-    for v in (15, 16, 12):
+    for v in (15, 16, 17, 18, 19, 12):
         assert np.array_equal(_run(gpu, hvd, db, v, cap=len(want) + 16), want), v
 
 
