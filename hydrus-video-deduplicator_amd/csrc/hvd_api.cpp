@@ -560,7 +560,7 @@ int hvd_debug_set(const char* key, int value) {
         return HVD_OK;
     }
     if (strcmp(key, "mfma_auto_mid") == 0) {  // form the auto variant runs on data with common false survivors
-        if (value != 0 && value != 15 && value != 16) return fail(HVD_ERR_ARG, "mfma_auto_mid: 15 / 16 (pair-queue forms) or 0 (none: fetch or register form only)");
+        if (value != 0 && (value < 15 || value > 19)) return fail(HVD_ERR_ARG, "mfma_auto_mid: 15 .. 19 (pair-queue forms) or 0 (none: fetch or register form only)");
         hvd::g_mfma_auto_mid = (uint32_t)value;
         return HVD_OK;
     }
