@@ -612,29 +612,30 @@ __device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, ui
     }
 }
 
-// ---- panel-mark queue (QUEUE = 2) -------------------------------------------------------------------------------------
+// ---- panel-mark queue (QUEUE = 2, 3, 4: variants 17, 18, 19) ---------------------------------------------------------------
 // What the group-mask queue above still pays in the panel loop -- a taken branch and ~11 VALU instructions per SURVIVING TILE,
-// a fifth of all tiles of a frame-hash library, executed by a whole wave for the one lane that holds the survivor -- moves
-// behind the barrier as well: the panel loop is the fetch form's (one v_alignbit per tile shifts the tile's verdict into a
-// per-lane mask), and per PANEL the lanes whose mask is not empty push it, with their column, branch-free (a ballot, two
-// counts, one predicated ds_write_b64). Which of the lane's 16 rows of a marked tile it was is not recorded at all: the
-// settlement filters all 16 against the column on the 128 bits the first stage did not see -- 16 LDS reads and ~150 VALU
-// operations of ONE lane per entry instead of six wave-wide instructions per surviving tile in the loop.
-// entry: x = the lane's tile marks (bit TILES-1-t <-> tile t); y as above. The filter writes back the marks of the tiles in
-// which some row passed (x = 0: nothing left), settle_marked_panel_wg walks those again and settles every passing row.
+// a fifth of all tiles of a frame-hash library, executed by a whole wave for the one lane that holds the survivor (1.2 + 0.4 ms
+// of 18.1 on 4.2e11 comparisons) -- moves behind the barrier as well: the panel loop is the fetch form's (v_alignbit shifts
+// a tile's verdict into a per-lane mask), and once per PANEL the lanes whose mask is not empty push it, with their column,
+// branch-free: a ballot, two counts, one predicated ds_write_b64 -- free next to 16 MFMAs (ablation: pushing and dropping costs
+// what not pushing costs). WHICH of the lane's rows it was is recorded only as far as the OR tree is cut: a mark stands for
+// 16 / Q accumulator registers of one tile (Q = 1, 2, 4 marks per tile, one v_alignbit each); registers 4c .. 4c+3 are four
+// CONSECUTIVE rows, ibrel + 8c + 0..3 (qrow_of). Mark number idx = t * Q + q sits in bit (TILES * Q - 1 - idx) of the mask.
+// The settlement filters a mark's 16 / Q rows against the column on the 128 bits the first stage did not see -- the work
+// of ONE lane per entry instead of wave-wide instructions per surviving tile in the loop. Q = 2 measures best (same box,
+// ms: Q = 1: 18.0, 2: 17.15, 4: 17.6; group masks: 18.25 -- the filter costs 0.2 + 0.125 ms per row of a mark, a mark 0.25 ms
+// in the loop). entry: x = the lane's marks; y as above. The filter writes back the marks that hold a HIT (x = 0: nothing
+// left; see HVD_K2_QFULL below), settle_marked_panel_wg walks those again and reports every row that passes in full.
 constexpr uint32_t kQPanelLanes = 16;  // a panel in which more lanes than this hold a survivor takes the tile route
 
-// A mark stands for 16 / Q accumulator registers of one tile (Q = 1, 2, 4 marks per tile: the OR tree is cut into as many
-// parts, one v_alignbit each); registers 4c .. 4c+3 are four CONSECUTIVE rows, ibrel + 8c + 0..3 (qrow_of). Mark number
-// idx = t * Q + q sits in bit (TILES * Q - 1 - idx) of a lane's mask.
 #ifndef HVD_K2_QROT
-#define HVD_K2_QROT 1
+#define HVD_K2_QROT 1  // A/B: the filter's lanes walk their four rows in an order rotated by the lane number (measured neutral)
+#endif
+#ifndef HVD_K2_QE
+#define HVD_K2_QE 3  // entries a thread of the panel-mark settlement takes per round (2 .. 5 with matching kQDrainAt: within 1.5 %)
 #endif
 #ifndef HVD_K2_QFULL
-#define HVD_K2_QFULL 1
-#endif
-#ifndef HVD_K2_QSPLIT
-#define HVD_K2_QSPLIT 0
+#define HVD_K2_QFULL 1  // A/B: a row that passes the filter is checked on the first stage's half as well, on the spot (-3.4 %)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 // Does any of four consecutive rows pass? Every lane's four rows start at a multiple of 64 bytes, so a ds_read_b128 that
@@ -670,7 +671,7 @@ __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict_
 #endif
     const uint32_t oh = ohw & 1u, wrows = ohw >> 8;
     const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;
-    constexpr int E = 3;
+    constexpr int E = HVD_K2_QE;
     uint32_t left = 0;
     bool staged = false;
 #pragma unroll 1
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
     // QUEUE: entries per wave, and the most one wave can add between two barriers
     constexpr int QG = QUEUE == 2 ? 1 : QUEUE == 3 ? 2 : QUEUE == 4 ? 4 : 0;  // panel-mark queue: marks per tile
     static_assert(TILES * QG <= 32, "a lane's marks are one word");
-    constexpr uint32_t QCAP = kQEntries / WAVES, QSUPERMAX = (kSuper / 32) * (QUEUE >= 2 ? (HVD_K2_QSPLIT ? 2u : 1u) * kQPanelLanes : TILES * kQTileLanes);
+    constexpr uint32_t QCAP = kQEntries / WAVES, QSUPERMAX = (kSuper / 32) * (QUEUE >= 2 ? kQPanelLanes : TILES * kQTileLanes);
     static_assert(!QUEUE || QCAP >= QSUPERMAX + 64, "a wave's queue must take a super-panel's worth on top of a carry-over");
     __shared__ uint4 lds0[kSuper * 8], lds1[kSuper * 8];
 
@@ -966,21 +967,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
 #if defined(HVD_K2_QABL) && (HVD_K2_QABL == 8 || HVD_K2_QABL == 10)  // timing-only ablation (wrong results): survivors are counted, nothing is pushed
                 asm volatile("" ::"s"(nl));
 #else
-                // One mark per entry: the settlement's lanes take an entry each and walk its marks, so a wave is as slow as its
-                // lane with the most -- and 6 % of the lanes that push hold two (two tiles of one column): 98 % of the waves
-                // would walk twice for them. A lane's lowest mark goes into one entry, whatever else it holds into a second.
-                const uint32_t low = HVD_K2_QSPLIT ? marks & (0u - marks) : marks, rest = marks ^ low;
-                const unsigned long long act2 = __ballot(rest != 0u);
-                const uint32_t nl2 = (uint32_t)__builtin_popcount((uint32_t)act2) + (uint32_t)__builtin_popcount((uint32_t)(act2 >> 32));
+                // (a second entry for the lanes that hold two marks -- 6 % of those that push; a settling wave is as slow as its
+                // lane with the most -- was measured: +1.5 %, the extra ballot and push in this loop cost more than they save)
                 if (marks != 0u && !dense) {
                     const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-                    g_wave_queue[qidx + mb] = make_uint2(low, ((jsp + 32u * p) << 1) + qcol);
+                    g_wave_queue[qidx + mb] = make_uint2(marks, ((jsp + 32u * p) << 1) + qcol);
                 }
-                if (rest != 0u && !dense) {
-                    const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act2, 0u));
-                    g_wave_queue[qidx + nl + mb] = make_uint2(rest, ((jsp + 32u * p) << 1) + qcol);
-                }
-                qidx += dense ? 0u : nl + nl2;
+                qidx += dense ? 0u : nl;
 #endif
                 if (__builtin_expect(dense, 0)) {
                     uint32_t tm = marks;  // one bit per tile for the tile route
