@@ -626,7 +626,12 @@ __device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, ui
 // ms: Q = 1: 18.0, 2: 17.15, 4: 17.6; group masks: 18.25 -- the filter costs 0.2 + 0.125 ms per row of a mark, a mark 0.25 ms
 // in the loop). entry: x = the lane's marks; y as above. The filter writes back the marks that hold a HIT (x = 0: nothing
 // left; see HVD_K2_QFULL below), settle_marked_panel_wg walks those again and reports every row that passes in full.
-constexpr uint32_t kQPanelLanes = 16;  // a panel in which more lanes than this hold a survivor takes the tile route
+#ifndef HVD_K2_QPANEL_LANES
+#define HVD_K2_QPANEL_LANES 48
+#endif
+// a panel in which more lanes than this hold a survivor takes the tile route (16 / 32 / 48: the form beats the register form
+// up to 1.5 / 3.5 / 6.5 first-stage survivors per tile, profiles/r04_k2_queue_ablation.txt; a tile full of hits has 64)
+constexpr uint32_t kQPanelLanes = HVD_K2_QPANEL_LANES;
 
 #ifndef HVD_K2_QROT
 #define HVD_K2_QROT 1  // A/B: the filter's lanes walk their four rows in an order rotated by the lane number (measured neutral)
@@ -1275,8 +1280,9 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
 uint32_t g_mfma_lds_pad = 0;  // occupancy experiments: unused dynamic LDS per workgroup (hvd_debug_set "mfma_lds_pad")
 uint32_t g_mfma_queue_packed = 1;  // 0: the pair queue settles from the FP4 images even when packed hashes are at hand (tests)
 uint32_t g_mfma_auto_mid = 18;
-uint32_t g_mfma_auto_mid_max_x100 = 130;  // (scripts/gpu_k2_rate_sweep.py: the queue form wins up to ~1 survivor per tile -- 0.77-0.82 of the
-                                          // register form's time at 0.06-1.0 -- and loses from 2 on: 1.15x at 2, 2.4x at 4, the tile route)
+uint32_t g_mfma_auto_mid_max_x100 = 500;  // (scripts/gpu_k2_rate_sweep.py: the panel-mark queue takes 0.61-0.67 of the register form's time
+                                          // at 1-2.7 survivors per tile, 0.79 at 4, 0.88 at 5.3, 1.23 at 8; round 4's first queue form, 15,
+                                          // won up to ~1 and the boundary was 1.3)
 hipError_t launch_pack_fp4(const void* d_img, uint32_t n, void* d_db, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint64_t threads = (uint64_t)n * 8u;

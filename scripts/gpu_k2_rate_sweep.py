@@ -16,7 +16,7 @@ for P in [int(x) for x in os.environ.get("PS", "16384,8192,4096,2048,1024,512,25
     d_db = L.DeviceBuffer.from_array(db)
     d_img = M.expand_fp4(d_db.ptr, n)
     res = {}
-    for v in (12, 15, 18):
+    for v in (12, 15, 18, 13):
         ks = []
         for r in range(4):
             d_cnt.zero()
@@ -25,5 +25,5 @@ for P in [int(x) for x in os.environ.get("PS", "16384,8192,4096,2048,1024,512,25
             ms = C.c_float(0); L.check(lib.hvd_timer_stop(C.byref(ms)))
             if r: ks.append(ms.value)
         res[v] = (np.mean(ks), int(d_cnt.to_array(np.uint64, 1)[0]))
-    print(f"P={P:6d} survivors/tile {1024 / P:6.3f}: form 12 {res[12][0]:8.3f} ms  form 15 {res[15][0]:8.3f} ms  form 18 {res[18][0]:8.3f} ms  ratio 15/12 {res[15][0] / res[12][0]:.3f}  18/12 {res[18][0] / res[12][0]:.3f}  pairs {res[12][1]} {res[15][1]} {res[18][1]}", flush=True)
+    print(f"P={P:6d} survivors/tile {1024 / P:6.3f}: form 12 {res[12][0]:8.3f} ms  form 15 {res[15][0]:8.3f} ms  form 18 {res[18][0]:8.3f} ms  ratio 15/12 {res[15][0] / res[12][0]:.3f}  18/12 {res[18][0] / res[12][0]:.3f}  auto {res[13][0]:8.3f} ms  pairs {res[12][1]} {res[15][1]} {res[18][1]} {res[13][1]}", flush=True)
     d_db.free(); d_img.free()
