@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 G1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS"
 G2="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 G3="SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_IFETCH SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD"
-for tag in ${@:-structured15 structured12 uniform9}; do
+for tag in ${@:-structured18 structured15 structured12 uniform9}; do
   case $tag in
     structured*) CMD="python $REPO/scripts/gpu_k2_structured.py ${tag#structured}"; export V=16000;;
     uniform*) CMD="python $REPO/scripts/prof_driver.py 920000 ${tag#uniform}";;

@@ -26,6 +26,6 @@ for N in 10000 400000; do
 done
 bash scripts/profile_rgb.sh r04_rgb 2 stats sq1 sq2 fetch wr tcc > /dev/null 2>&1
 python scripts/pmc_summary.py gpurun_out/pmc_r04_rgb > gpurun_out/r04_pmc_down512w.txt 2>&1
-# structured K2: pair-queue form (15) vs register form (12) on config-5-style frame hashes, fetch form (9) on uniform hashes
-bash scripts/profile_k2_r04.sh structured15 structured12 uniform9 > /dev/null 2>&1
+# structured K2: panel-mark queue (18) and group-mask queue (15) vs register form (12) on config-5-style frame hashes, fetch form (9) on uniform hashes
+bash scripts/profile_k2_r04.sh structured18 structured15 structured12 uniform9 > /dev/null 2>&1
 echo "profile set done"
