@@ -596,7 +596,9 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                                     "frac": round(flop5 / (search5_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS, 4),
                                     "flop_per_launch": flop5,
                                     "basis": "first-stage MFMAs only (2 per 1024 executed comparisons, per rank) over the time of the "
-                                             "whole call; counters: profiles/r04_pmc_k2_structured18.txt", "traffic": None}}
+                                             "whole call; counters: profiles/r04_pmc_k2_structured18.txt, profiles/r04_pmc_cfg5.txt",
+                                    "traffic": load_traffic(f"config5_search_v{V}x{F}_w{world}"),
+                                    "traffic_source": TRAFFIC_SOURCE}}
             extras["cfg5"] = {"workload": f"BASELINE configs[4]: {V} synthetic videos x {F} distinct 64x64 frames generated in HBM -> PDQ hash -> "
                                 "quality filter + CSR on the GPU -> FP4 image -> all video pairs with the vPDQ counters reduced on "
                                 f"the GPU -> pair predicate (threshold 50); {world} GPU(s): frames hashed in disjoint video ranges, "
