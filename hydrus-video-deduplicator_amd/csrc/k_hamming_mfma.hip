@@ -1181,19 +1181,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
 
 // Probe for the data-dependent choice of the kernel form: over a strided sample of the two images (up to 4096 rows
 // x 4096 columns), how often do the first 128 bits of two hashes agree to within the tolerance? In the FP4 image a
-// differing bit is a differing sign nibble, so the partial distance is popcount((x ^ y) & 0x88888888) over chunks
-// 0..3. One lane per sample row, 256 sample columns per workgroup broadcast from LDS. select[1] += survivors.
+// differing bit is a differing sign nibble, so the partial distance is popcount(x ^ y) over chunks 0..3.
+// One lane per sample row, 64 sample columns per workgroup broadcast from LDS. select[1] += survivors.
 constexpr uint32_t kProbeRows = 4096, kProbeCols = 4096;
 
-__device__ __forceinline__ uint32_t sign_diff(const uint4& x, const uint4& y) {
-    return __popc((x.x ^ y.x) & 0x88888888u) + __popc((x.y ^ y.y) & 0x88888888u) + __popc((x.z ^ y.z) & 0x88888888u) +
-           __popc((x.w ^ y.w) & 0x88888888u);
-}
+// (round 4: 64 sample columns per workgroup instead of 256 -- 1024 workgroups instead of 256, four waves per SIMD instead of a
+// lone one whose dependent popcount chain issues every ~5 cycles: 78 -> ~25 us per pass; sampled hashes are real ones, whose
+// images differ in sign nibbles only, so the XOR needs no mask)
+constexpr uint32_t kProbeColsPerWg = 64;
+struct ProbeRule {  // survivors among `pairs` sampled pairs -> form (probe_decide, below)
+    uint64_t pairs;
+    uint32_t pairs_per_step, id_rare, id_mid, id_often;
+    float mid_max_per_tile;
+};
+__device__ void probe_decide(uint32_t* __restrict__ select, uint32_t lo, uint32_t hi, const ProbeRule& rule);
 
 __global__ __launch_bounds__(256) void k_prefilter_probe(const uint4* __restrict__ img_q, uint32_t nq,
                                                          const uint4* __restrict__ img_t, uint32_t nt, uint32_t max_dist,
-                                                         uint32_t* __restrict__ select) {
-    __shared__ uint4 cols[256][8];
+                                                         uint32_t* __restrict__ select, const ProbeRule rule) {
+    __shared__ uint4 cols[kProbeColsPerWg][8];
     const uint32_t rows = min(nq, kProbeRows), ncols = min(nt, kProbeCols);
     const uint32_t rstride = nq / rows, cstride = nt / ncols;
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
@@ -1202,18 +1208,20 @@ __global__ __launch_bounds__(256) void k_prefilter_probe(const uint4* __restrict
 #pragma unroll
     for (uint32_t c = 0; c < 8; ++c) q[c] = img_q[(size_t)ri * 8u + img_slot(ri, c)];
     // columns sit half a stride off the rows so that, in the symmetric form, a sample row never meets itself
-    const uint32_t c = blockIdx.y * 256u + threadIdx.x;
-    const uint32_t ci = min(min(c, ncols - 1u) * cstride + cstride / 2u, nt - 1u);
-#pragma unroll
-    for (uint32_t k = 0; k < 8; ++k) cols[threadIdx.x][k] = img_t[(size_t)ci * 8u + img_slot(ci, k)];
+    {
+        const uint32_t cl = threadIdx.x >> 2, k0 = (threadIdx.x & 3u) * 2u;  // four threads fetch one column's eight chunks
+        const uint32_t c = blockIdx.y * kProbeColsPerWg + cl;
+        const uint32_t ci = min(min(c, ncols - 1u) * cstride + cstride / 2u, nt - 1u);
+        cols[cl][k0] = img_t[(size_t)ci * 8u + img_slot(ci, k0)];
+        cols[cl][k0 + 1u] = img_t[(size_t)ci * 8u + img_slot(ci, k0 + 1u)];
+    }
     __syncthreads();
-    const uint32_t m = blockIdx.y * 256u >= ncols ? 0u : min(256u, ncols - blockIdx.y * 256u);
+    const uint32_t c0 = blockIdx.y * kProbeColsPerWg;
+    const uint32_t m = c0 >= ncols ? 0u : min(kProbeColsPerWg, ncols - c0);
     uint32_t cnt = 0, cnt_hi = 0;  // survivors of a first stage over bits 0..127 / over bits 128..255
     for (uint32_t k = 0; k < m; ++k) {
-        const uint32_t d = sign_diff(q[0], cols[k][0]) + sign_diff(q[1], cols[k][1]) + sign_diff(q[2], cols[k][2]) +
-                           sign_diff(q[3], cols[k][3]);
-        const uint32_t d_hi = sign_diff(q[4], cols[k][4]) + sign_diff(q[5], cols[k][5]) + sign_diff(q[6], cols[k][6]) +
-                              sign_diff(q[7], cols[k][7]);
+        const uint32_t d = sign_popc(q[0], cols[k][0], sign_popc(q[1], cols[k][1], sign_popc(q[2], cols[k][2], sign_popc(q[3], cols[k][3], 0u))));
+        const uint32_t d_hi = sign_popc(q[4], cols[k][4], sign_popc(q[5], cols[k][5], sign_popc(q[6], cols[k][6], sign_popc(q[7], cols[k][7], 0u))));
         cnt += d <= max_dist ? 1u : 0u;
         cnt_hi += d_hi <= max_dist ? 1u : 0u;
     }
@@ -1222,32 +1230,55 @@ __global__ __launch_bounds__(256) void k_prefilter_probe(const uint4* __restrict
         cnt += __shfl_down(cnt, off);
         cnt_hi += __shfl_down(cnt_hi, off);
     }
+    // one pair of atomics per WORKGROUP (same-address device atomics take ~8 ns each: per wave they were 65 us of a probe over
+    // frame hashes), and the workgroup that finishes last turns the two sums into the decision -- one launch less per pass (a
+    // one-lane kernel costs ~5 us plus the gap in front of it). No fence anywhere: the sums travel in atomics, which are
+    // performed at the memory side, and a workgroup takes its ticket (select[4], zeroed by k_set_hit_ctx with the rest) only
+    // after its own additions have RETURNED.
+    __shared__ uint32_t part[2][4];
     if ((threadIdx.x & 63u) == 0u) {
-        if (cnt) atomicAdd(&select[1], cnt);
-        if (cnt_hi) atomicAdd(&select[2], cnt_hi);
+        part[0][threadIdx.x >> 6] = cnt;
+        part[1][threadIdx.x >> 6] = cnt_hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t c_lo = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        const uint32_t c_hi = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        uint32_t seen = 0;
+        if (c_lo) seen += atomicAdd(&select[1], c_lo);
+        if (c_hi) seen += atomicAdd(&select[2], c_hi);
+        asm volatile("" ::"v"(seen));  // (the returning form, and its result waited for)
+        if (atomicAdd(&select[4], 1u) == gridDim.x * gridDim.y - 1u)
+            probe_decide(select, atomicAdd(&select[1], 0u), atomicAdd(&select[2], 0u), rule);
     }
 }
 
 // The hit handler's launch-uniform arguments live in device memory (written by this one-lane kernel in stream order
 // in front of the pass), so that the rare handler call passes one pointer instead of ~30 argument registers that the
 // fast path's register allocation would have to keep clear.
-__global__ void k_set_hit_ctx(HitCtx* __restrict__ dst, const HitCtx src) { *dst = src; }
+// (select != nullptr: the auto variant's launch -- the probe's words are cleared in the same launch)
+__global__ void k_set_hit_ctx(HitCtx* __restrict__ dst, const HitCtx src, uint32_t* __restrict__ select) {
+    *dst = src;
+    if (select != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) select[k] = 0u;
+    }
+}
 
 // survivors among `pairs` sampled pairs -> form. The fetch form (id_rare) pays ~6 panel steps per surviving TILE: right when
-// survivors are real near-duplicates (uniform random hashes). The pair-queue form (id_mid) pays ~40 VALU instructions per
-// surviving tile and nothing on the matrix pipe: right for real frame hashes, whose first 128 bits agree within the tolerance
-// for ~2e-4 of unrelated pairs. The register form (id_often) pays one MFMA per surviving tile however many pairs survive in
-// it: right when most tiles hold several survivors (a library whose hashes barely differ in either half).
-__global__ void k_probe_decide(uint32_t* __restrict__ select, uint64_t pairs, uint32_t pairs_per_step, uint32_t id_rare,
-                               uint32_t id_mid, uint32_t id_often, float mid_max_per_tile) {
+// survivors are real near-duplicates (uniform random hashes). The pair-queue form (id_mid) pays the settlement of one queue
+// entry per surviving lane and nothing on the matrix pipe: right for real frame hashes, whose first 128 bits agree within the
+// tolerance for ~2e-4 of unrelated pairs. The register form (id_often) pays one MFMA per surviving tile however many pairs
+// survive in it: right when most tiles hold several survivors (a library whose hashes barely differ in either half).
+__device__ void probe_decide(uint32_t* __restrict__ select, uint32_t lo, uint32_t hi, const ProbeRule& rule) {
     // first the half: the one whose 128 bits let fewer unrelated pairs through (ties and near-ties stay with bits 0..127,
     // so that uniform data always runs the same configuration); then the form, from that half's rate
-    const uint32_t lo = select[1], hi = select[2];
     const bool use_hi = (double)hi * 1.25 < (double)lo;
     select[3] = use_hi ? 1u : 0u;
-    const double rate = pairs ? (double)(use_hi ? hi : lo) / (double)pairs : 0.0;
-    uint32_t form = id_rare;
-    if (rate * (double)pairs_per_step > 0.01) form = (id_mid != 0u && rate * 1024.0 <= (double)mid_max_per_tile) ? id_mid : id_often;
+    const double rate = rule.pairs ? (double)(use_hi ? hi : lo) / (double)rule.pairs : 0.0;
+    uint32_t form = rule.id_rare;
+    if (rate * (double)rule.pairs_per_step > 0.01)
+        form = (rule.id_mid != 0u && rate * 1024.0 <= (double)rule.mid_max_per_tile) ? rule.id_mid : rule.id_often;
     select[0] = form;
 }
 
@@ -1362,7 +1393,8 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
 // One launch of one form. rect: rows = the nq hashes of d_img_q, columns = the a.n hashes of d_img.
 template <int T, int NBR, int S1, int QUEUE = 0, int WAVES = 4>
 static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q, uint32_t nq,
-                              const int32_t* d_group_t, const uint32_t* d_select, uint32_t select_id, hipStream_t s) {
+                              const int32_t* d_group_t, const uint32_t* d_select, uint32_t select_id, hipStream_t s,
+                              bool write_ctx = true) {
     const uint32_t n_pad = fp4_rows_padded(a.n);
     constexpr uint32_t ROWS = 32u * T * WAVES;
     const uint32_t nrows = rect ? nq : a.n;
@@ -1383,7 +1415,10 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
     hipError_t e = mfma_select_buffer(a.ctx_id, &buf);
     if (e != hipSuccess) return e;
     HitCtx* ctx = reinterpret_cast<HitCtx*>(buf + 16);
-    hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1, rect ? d_img_q : d_img, d_img));
+    // (the auto variant writes one context for its three launches: they share S1, the only form-dependent field)
+    if (write_ctx)
+        hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1, rect ? d_img_q : d_img, d_img),
+                           (uint32_t*)nullptr);
     if (rect)
         hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE, WAVES>), grid, dim3(64 * WAVES), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
@@ -1396,19 +1431,20 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
 }
 
 static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q,
-                                 uint32_t nq, const int32_t* d_group_t, const uint32_t* d_select, hipStream_t s) {
+                                 uint32_t nq, const int32_t* d_group_t, const uint32_t* d_select, hipStream_t s,
+                                 bool write_ctx = true) {
     switch (variant) {
-        case 8: return launch_form<8, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 8u, s);
-        case 9: return launch_form<8, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 9u, s);
-        case 10: return launch_form<4, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 10u, s);
-        case 11: return launch_form<4, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 11u, s);
-        case 12: return launch_form<4, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 12u, s);
-        case 14: return launch_form<8, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 14u, s);
-        case 15: return launch_form<8, 2, 2, 1>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 15u, s);
-        case 16: return launch_form<4, 2, 2, 1, 8>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 16u, s);
-        case 17: return launch_form<8, 2, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 17u, s);
-        case 18: return launch_form<8, 2, 2, 3>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 18u, s);
-        case 19: return launch_form<8, 2, 2, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 19u, s);
+        case 8: return launch_form<8, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 8u, s, write_ctx);
+        case 9: return launch_form<8, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 9u, s, write_ctx);
+        case 10: return launch_form<4, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 10u, s, write_ctx);
+        case 11: return launch_form<4, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 11u, s, write_ctx);
+        case 12: return launch_form<4, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 12u, s, write_ctx);
+        case 14: return launch_form<8, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 14u, s, write_ctx);
+        case 15: return launch_form<8, 2, 2, 1>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 15u, s, write_ctx);
+        case 16: return launch_form<4, 2, 2, 1, 8>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 16u, s, write_ctx);
+        case 17: return launch_form<8, 2, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 17u, s, write_ctx);
+        case 18: return launch_form<8, 2, 2, 3>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 18u, s, write_ctx);
+        case 19: return launch_form<8, 2, 2, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 19u, s, write_ctx);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1460,23 +1496,24 @@ static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rec
     uint32_t* sel = nullptr;
     hipError_t e = mfma_select_buffer(a.ctx_id, &sel);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(sel, 0, 16, s);
-    if (e != hipSuccess) return e;
+    // one launch writes the hit context of all three forms (they share S1 = 2) and clears the probe's words; the probe's last
+    // workgroup decides. Per pass: context, probe, three forms -- five launches where there were nine.
+    hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, reinterpret_cast<HitCtx*>(sel + 16),
+                       hit_ctx(a, rect, nq, d_group_t, 2, rect ? d_img_q : d_img, d_img), sel);
     const uint32_t nrows = rect ? nq : a.n;
     const uint32_t rows = nrows < kProbeRows ? nrows : kProbeRows, cols = a.n < kProbeCols ? a.n : kProbeCols;
-    hipLaunchKernelGGL(k_prefilter_probe, dim3((rows + 255u) / 256u, (cols + 255u) / 256u), dim3(256), 0, s,
-                       (const uint4*)(rect ? d_img_q : d_img), nrows, (const uint4*)d_img, a.n, a.max_dist, sel);
     // (the pair queue keeps (column << 1 | half) in 32 bits)
     const uint32_t mid = fp4_rows_padded(a.n) < (1u << 31) ? g_mfma_auto_mid : 0u;
-    hipLaunchKernelGGL(k_probe_decide, dim3(1), dim3(1), 0, s, sel, (uint64_t)rows * cols, 8192u, 9u, mid, 12u,
-                       0.01f * (float)g_mfma_auto_mid_max_x100);
-    e = launch_variant(9, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
+    const ProbeRule rule = {(uint64_t)rows * cols, 8192u, 9u, mid, 12u, 0.01f * (float)g_mfma_auto_mid_max_x100};
+    hipLaunchKernelGGL(k_prefilter_probe, dim3((rows + 255u) / 256u, (cols + kProbeColsPerWg - 1u) / kProbeColsPerWg), dim3(256), 0, s,
+                       (const uint4*)(rect ? d_img_q : d_img), nrows, (const uint4*)d_img, a.n, a.max_dist, sel, rule);
+    e = launch_variant(9, a, d_img, rect, d_img_q, nq, d_group_t, sel, s, false);
     if (e != hipSuccess) return e;
     if (mid) {
-        e = launch_variant((int)mid, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
+        e = launch_variant((int)mid, a, d_img, rect, d_img_q, nq, d_group_t, sel, s, false);
         if (e != hipSuccess) return e;
     }
-    return launch_variant(12, a, d_img, rect, d_img_q, nq, d_group_t, sel, s);
+    return launch_variant(12, a, d_img, rect, d_img_q, nq, d_group_t, sel, s, false);
 }
 
 static int effective_variant(int variant, uint32_t max_dist, uint32_t n) {

@@ -76,6 +76,28 @@ def test_k2_probe_picks_the_pair_queue_on_frame_hashes(gpu, hvd, oracle, frame_l
         assert np.array_equal(_run(gpu, hvd, frames, v, cap=1 << 20), want_all), v
 
 
+def test_k2_probe_counts_what_a_host_restatement_of_its_sample_counts(gpu, hvd, frame_library):
+    """k_prefilter_probe: up to 4096 sample rows x 4096 sample columns (strided, columns half a stride off the rows), survivors
+    of a 128-bit first stage over bits 0..127 and over bits 128..255 -- the two numbers the form choice rests on."""
+    frames, offsets, video, _ = frame_library
+    for db in (frames, frames[:3001], np.random.default_rng(5).integers(0, 256, (5000, 32), dtype=np.uint8)):
+        n = len(db)
+        _run(gpu, hvd, db, 13, cap=1 << 20)
+        rows = min(n, 4096)
+        rstride = cstride = n // rows
+        ri = np.arange(rows) * rstride
+        ci = np.minimum(np.arange(rows) * cstride + cstride // 2, n - 1)
+        lo = np.unpackbits(db[ri][:, None, :16] ^ db[ci][None, :, :16], axis=2).sum(2) if rows <= 1024 else None
+        want = [0, 0]
+        for h, sl in enumerate((slice(0, 16), slice(16, 32))):
+            a, b = db[ri][:, sl], db[ci][:, sl]
+            for r0 in range(0, rows, 256):  # (blocked: 4096 x 4096 x 128 bits at once would be 2 GB)
+                d = np.unpackbits(a[r0:r0 + 256, None, :] ^ b[None, :, :], axis=2).sum(2)
+                want[h] += int((d <= 31).sum())
+        assert lo is None or int((lo <= 31).sum()) == want[0]
+        assert [_auto(gpu, b"mfma_probe_survivors"), _auto(gpu, b"mfma_probe_survivors_hi")] == want, n
+
+
 def test_k2_pair_queue_settles_from_the_images_when_there_are_no_packed_hashes(gpu, hvd, oracle, frame_library):
     frames, offsets, video, _ = frame_library
     sub = frames[:30000]
