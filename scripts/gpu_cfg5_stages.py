@@ -6,6 +6,7 @@ import hvd_amd
 from hvd_amd import _lib as L, pipeline, search
 
 lib = L.init(0)
+if os.environ.get("CHUNK"): L.check(lib.hvd_debug_set(b"mfma_col_chunk_max", int(os.environ["CHUNK"])))
 V, F = int(os.environ.get("V", 50000)), 64
 n = V * F
 d_frames = L.DeviceBuffer(n * 4096)

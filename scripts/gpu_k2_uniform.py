@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hvd_amd
 from hvd_amd import _lib as L, multigpu as M, synth
 lib = L.init(0)
+if os.environ.get("CHUNK"): L.check(lib.hvd_debug_set(b"mfma_col_chunk_max", int(os.environ["CHUNK"])))
 n = int(os.environ.get("N", 1_000_000))
 db, _ = synth.hash_db(n, seed=3)
 d_db = L.DeviceBuffer.from_array(db)
