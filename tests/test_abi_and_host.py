@@ -219,17 +219,17 @@ def test_compiled_dct_table_is_the_host_matrix(hvd, oracle):
 
 
 # ---------------------------------------------------------------- round 4: the in-process device group -------------------
-@pytest.mark.parametrize("variant", [9, 12, 13, 15])
+@pytest.mark.parametrize("variant", [9, 12, 13, 15, 18])
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_in_process_split_is_the_same_partition_for_every_form_the_probe_may_pick(hvd, world, variant):
     """The contexts of a device group take tile (rb, cb) by (rb + cb) % world like the ranks of the process-per-GPU mode
     (same kernel argument). The probe picks the form on the device, identically on every context (replicated DB); whatever
-    it picks, the shares must tile the upper triangle exactly once -- including the round-4 pair-queue form (15), whose
-    workgroup covers the fetch form's 1024 rows."""
+    it picks, the shares must tile the upper triangle exactly once -- including the round-4 pair-queue forms (15, and 18: the
+    one the probe picks on frame hashes), whose workgroups cover the fetch form's 1024 rows."""
     from hvd_amd import multigpu as M
 
     n = 70_000
-    assert M.tile_geometry(n, 15) == M.tile_geometry(n, 9)
+    assert M.tile_geometry(n, 15) == M.tile_geometry(n, 9) == M.tile_geometry(n, 18)
     area = 0
     for r in range(world):
         for row0, row1, col0, col1 in M.tiles_of_rank(n, r, world, variant=variant):
