@@ -53,3 +53,29 @@ def test_copy_pool_odd_sizes_and_thread_counts(hvd):
             dst = np.full(n + 16, 0xA5, dtype=np.uint8)
             assert lib.hvd_debug_parallel_copy(dst.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p) if n else None, n, threads) == 0
             assert np.array_equal(dst[:n], src) and (dst[n:] == 0xA5).all(), (n, threads)
+
+
+def test_copy_pool_under_thread_sanitizer(tmp_path):
+    """The pool is header-only (csrc/copy_pool.h, no HIP), so the same stress -- four callers with different thread counts
+    and sizes on one pool, stop/restart, helpers falling asleep -- is also built with g++ -fsanitize=thread and run: any
+    unsynchronised access to a mailbox, the ticket or the pending counter is reported by the sanitizer (SURVEY section 5:
+    the reference has no race detection; this is the build's)."""
+    import os
+    import shutil
+    import subprocess
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        import pytest
+        pytest.skip("no g++")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "copy_pool_tsan.cpp")
+    exe = str(tmp_path / "copy_pool_tsan")
+    build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", src, "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in (build.stderr or "").lower():
+        import pytest
+        pytest.skip("ThreadSanitizer runtime not installed: " + build.stderr[-200:])
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "150"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "copy_pool_tsan ok" in run.stdout, (run.returncode, run.stdout[-500:], run.stderr[-3000:])
+    assert "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
