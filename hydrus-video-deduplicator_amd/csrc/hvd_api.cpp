@@ -91,6 +91,7 @@ struct Ctx {
     int v_exchange_mode = 0;          // hvd_debug_set("vmatch_exchange"): 0 exchange keys iff world > 1, 1 always, 2 never
     int v_fail_rank = 0;              // hvd_debug_set("vmatch_fail_rank"): rank + 1 whose local phase fails (tests the agreement step)
     int v_force_slots_log2 = 0;       // hvd_debug_set("vmatch_slots_log2"): start the tables this small (tests the regrowth)
+    int v_variant = 0;                // hvd_debug_set("vmatch_variant"): all-pairs form of the video-level searches, 0 = default (tests, fuzz)
     std::recursive_mutex h_mu;
 };
 constexpr int kMaxCtx = 16;
@@ -591,6 +592,11 @@ int hvd_debug_set(const char* key, int value) {
     if (strcmp(key, "vmatch_slots_log2") == 0) {
         if (value != 0 && (value < 4 || value > 30)) return fail(HVD_ERR_ARG, "vmatch_slots_log2: 0 (automatic) or 4..30");
         g.v_force_slots_log2 = value;
+        return HVD_OK;
+    }
+    if (strcmp(key, "vmatch_variant") == 0) {  // tests / scripts/gpu_fuzz_k3.py: the video-level searches through one explicit form
+        if (value != 0 && (value < 8 || value > 19)) return fail(HVD_ERR_ARG, "vmatch_variant: 0 (default) or an MFMA form 8..19");
+        g.v_variant = value;
         return HVD_OK;
     }
     if (strcmp(key, "vmatch_fail_rank") == 0) {  // tests: rank (value - 1) fails before the key exchange; 0 = off
@@ -1217,9 +1223,9 @@ int vmatch_build(const VmArgs& v) {
         a.d_pairs = nullptr;
         a.cap = 0;
         a.d_count = d_counters + 3;
-        a.variant = HVD_DEFAULT_VARIANT;
+        a.variant = g.v_variant ? g.v_variant : HVD_DEFAULT_VARIANT;
         a.col_chunk = 0;
-    a.ctx_id = t_ctx;
+        a.ctx_id = t_ctx;
         a.sink = hvd::VideoSink{d_set, slots - 1, d_counters, v.d_vid_q, v.d_vid_t};
         hipError_t e = v.rect ? hvd::launch_cross_mfma(a, v.d_img_q, v.nq, v.d_img_t, v.d_excl_t, g.stream)
                               : hvd::launch_allpairs_mfma(a, v.d_img_t, g.stream);
