@@ -275,3 +275,20 @@ def test_k1_next_frame_prefetch_switch_is_bit_identical(gpu, hvd, oracle):
             finally:
                 gpu.check(lib.hvd_debug_set(b"pdq_hash_prefetch", 0))
             assert np.array_equal(h, wh) and np.array_equal(q, wq), (n, pref)
+
+
+# ---------------------------------------------------------------- randomised sweeps (the dev tools, a few seeds each) ----
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,args", [("gpu_fuzz_k2.py", ["20", "12000"]), ("gpu_fuzz_k3.py", ["10", "1000"])])
+def test_randomised_parity_sweeps_of_the_pair_and_video_searches(script, args):
+    """scripts/gpu_fuzz_k2.py (frame pairs, every kernel form drawn at random) and scripts/gpu_fuzz_k3.py (video-level and
+    cross search through every form: ragged libraries with empty, one-frame and > 1024-frame videos, prototype-built halves,
+    copies around the tolerance) against the oracle; the long runs are recorded under profiles/."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "scripts", script)] + args, capture_output=True, text=True, timeout=1200)
+    assert run.returncode == 0 and " 0 mismatches" in run.stdout, (run.stdout[-1500:], run.stderr[-1500:])
