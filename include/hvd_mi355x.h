@@ -193,12 +193,18 @@ int hvd_get_pdq_dct_mode(void);
  *   "pdq_down512_wave" 0|1|2                               (wave-per-frame kernel: never | batches >= 704 | always)
  *   "pdq_down512_wave_grid" n                              (waves in flight; 0 = what is resident at once)
  *   "fp4_code", "mfma_col_chunk_max"                       (FP4-MFMA Hamming kernel)
+ *   "mfma_auto_mid" 0|15..19, "mfma_auto_mid_max_x100" n   (auto variant: the pair-queue form it may pick -- 18 -- and the survivor
+ *                                                           density per 1024-pair tile, x 0.01, up to which it does -- 500)
+ *   "mfma_queue_packed" 0|1, "mfma_lds_pad" bytes          (pair queue settles from the FP4 images only; occupancy experiments)
+ *   "pdq_hash_grid" n, "pdq_hash_prefetch" 0|1             (64x64 hash kernel: forced grid; next frame fetched ahead, off)
  *   "vmatch_exchange" 0|1|2                                (key exchange of the video search: iff world > 1 | always | never)
  *   "vmatch_slots_log2" 0|4..30                            (initial size of the video-reduction tables; tests the regrowth)
+ *   "vmatch_variant" 0|8..19                               (all-pairs form of the video-level searches; 0 = the auto variant)
  * Unknown keys and out-of-range values return HVD_ERR_ARG. */
 int hvd_debug_set(const char* key, int value);
-/* "mfma_auto_form": the form (9 or 12) the last variant-13 launch ran; "mfma_probe_survivors": what its probe counted.
- * Synchronises the library stream. */
+/* "mfma_auto_form": the form (9, 18 or 12; 15..19 if "mfma_auto_mid" says so) the last auto-variant launch ran;
+ * "mfma_probe_survivors" / "mfma_probe_survivors_hi": what its probe counted over bits 0..127 / 128..255; "mfma_auto_half":
+ * 1 if the first stage ran on bits 128..255. Synchronises the library stream. */
 int hvd_debug_get(const char* key, int* out_value);
 
 /* Bytes of device scratch hvd_dev_pdq_hash_frames needs for this geometry (0 for
