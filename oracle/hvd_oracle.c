@@ -615,3 +615,64 @@ int hvd_cpu_vpdq_match_videos(const uint8_t* frames, const int64_t* offsets, int
     *out_count = count;
     return count > cap ? HVD_ERR_OVERFLOW : HVD_OK;
 }
+
+/* The same brute force on num_threads host threads (bench.py's cpu_baseline wants every quota core, like the
+ * all-pairs scan): video a is handled by thread a % T (rows shrink with a, so dealing them round-robin balances the
+ * triangle), each thread keeps its records in (a, b) order in a private buffer, and the buffers are merged by a
+ * T-way walk over a. Every record comes from the single-thread statement above (hvd_cpu_match_two). */
+typedef struct {
+    const uint8_t* frames;
+    const int64_t* offsets;
+    int64_t V;
+    int max_dist, t, T;
+    hvd_vmatch* out;
+    int64_t cap, count;
+} vmatch_job;
+
+static void* vmatch_worker(void* arg) {
+    vmatch_job* jb = (vmatch_job*)arg;
+    for (int64_t a = jb->t; a < jb->V; a += jb->T)
+        for (int64_t b = a + 1; b < jb->V; ++b) {
+            int32_t q, t;
+            hvd_cpu_match_two(jb->frames + 32 * jb->offsets[a], jb->offsets[a + 1] - jb->offsets[a],
+                              jb->frames + 32 * jb->offsets[b], jb->offsets[b + 1] - jb->offsets[b], jb->max_dist, &q, &t);
+            if (q > 0 || t > 0) {
+                if (jb->count == jb->cap) {
+                    jb->cap = jb->cap ? 2 * jb->cap : 1024;
+                    jb->out = (hvd_vmatch*)realloc(jb->out, (size_t)jb->cap * sizeof(hvd_vmatch));
+                }
+                jb->out[jb->count++] = (hvd_vmatch){(uint32_t)a, (uint32_t)b, (uint32_t)q, (uint32_t)t};
+            }
+        }
+    return NULL;
+}
+
+int hvd_cpu_vpdq_match_videos_mt(const uint8_t* frames, const int64_t* offsets, int64_t V, int max_dist,
+                                 hvd_vmatch* out, int64_t cap, int64_t* out_count, int num_threads) {
+    if (V < 0 || !offsets || !out_count) return HVD_ERR_ARG;
+    int T = num_threads < 1 ? 1 : (num_threads > 256 ? 256 : num_threads);
+    if (T > V) T = V > 0 ? (int)V : 1;
+    vmatch_job jobs[256];
+    pthread_t th[256];
+    for (int t = 0; t < T; ++t) {
+        jobs[t] = (vmatch_job){frames, offsets, V, max_dist, t, T, NULL, 0, 0};
+        if (T == 1)
+            vmatch_worker(&jobs[t]);
+        else
+            pthread_create(&th[t], NULL, vmatch_worker, &jobs[t]);
+    }
+    for (int t = 0; t < T && T > 1; ++t) pthread_join(th[t], NULL);
+    int64_t count = 0, pos[256] = {0};
+    for (int64_t a = 0; a < V; ++a) { /* thread a % T holds row a's records next in its buffer */
+        vmatch_job* jb = &jobs[a % T];
+        int64_t* p = &pos[a % T];
+        while (*p < jb->count && jb->out[*p].a == (uint32_t)a) {
+            if (count < cap) out[count] = jb->out[*p];
+            count++;
+            (*p)++;
+        }
+    }
+    for (int t = 0; t < T; ++t) free(jobs[t].out);
+    *out_count = count;
+    return count > cap ? HVD_ERR_OVERFLOW : HVD_OK;
+}

@@ -59,6 +59,9 @@ def lib() -> C.CDLL:
         L.hvd_cpu_vpdq_match_videos.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                                 i64p]
         L.hvd_cpu_vpdq_match_videos.restype = C.c_int
+        L.hvd_cpu_vpdq_match_videos_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                                   i64p, C.c_int]
+        L.hvd_cpu_vpdq_match_videos_mt.restype = C.c_int
         _lib = L
     return _lib
 
@@ -172,17 +175,23 @@ def match_two(a: bytes, b: bytes, max_dist: int = 31) -> tuple[int, int]:
     return q.value, t.value
 
 
-def match_videos(frames: np.ndarray, offsets: np.ndarray, max_dist: int = 31, cap: int = 1 << 20) -> np.ndarray:
-    """All video pairs a<b with >=1 frame hit; structured array VMATCH_DTYPE sorted by (a,b)."""
+def match_videos(frames: np.ndarray, offsets: np.ndarray, max_dist: int = 31, cap: int = 1 << 20,
+                 num_threads: int = 1) -> np.ndarray:
+    """All video pairs a<b with >=1 frame hit; structured array VMATCH_DTYPE sorted by (a,b). num_threads > 1: the same
+    per-pair statement on several host threads (rows dealt round-robin), identical output."""
     frames = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, 32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     V = offsets.size - 1
     out = np.zeros(max(cap, 1), dtype=VMATCH_DTYPE)
     cnt = C.c_int64(0)
-    rc = lib().hvd_cpu_vpdq_match_videos(frames.ctypes.data, offsets.ctypes.data, V, max_dist, out.ctypes.data, cap,
-                                         C.byref(cnt))
+    if num_threads > 1:
+        rc = lib().hvd_cpu_vpdq_match_videos_mt(frames.ctypes.data, offsets.ctypes.data, V, max_dist, out.ctypes.data,
+                                                cap, C.byref(cnt), num_threads)
+    else:
+        rc = lib().hvd_cpu_vpdq_match_videos(frames.ctypes.data, offsets.ctypes.data, V, max_dist, out.ctypes.data, cap,
+                                             C.byref(cnt))
     if rc == -3:
-        return match_videos(frames, offsets, max_dist, cap=int(cnt.value))
+        return match_videos(frames, offsets, max_dist, cap=int(cnt.value), num_threads=num_threads)
     if rc != 0:
         raise RuntimeError(f"oracle match_videos rc={rc}")
     return out[: cnt.value].copy()
