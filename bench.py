@@ -133,6 +133,9 @@ def videohasher_stream_leg(lib, L, synth, vpdq):
       acquire_copy  acquire_frame() + np.copyto + commit_frame()   a decoder writing at memcpy speed into the pinned slot
       acquire_only  acquire_frame() + commit_frame()               the feed's own ceiling: slot contents left as the previous
                                                                    video wrote them (same frames, same positions)
+      acquire_run   acquire_frames(k) + ONE np.copyto per run + commit_frames()   a decoder that fills a run of frames per call
+      bytes_memcpy  hash_frame(bytes) with the ring copy as plain memcpy (hvd_debug_set copy_nt 0): the A/B of the
+                    non-temporal stores the copy slices use by default (round 5)
     Every video's hash is compared with the batch entry point's. Next to it: a pinned host->device bandwidth probe taken
     in the same run; `h2d_frac` = frame bytes/s over that probe."""
     out = {}
@@ -178,19 +181,36 @@ def videohasher_stream_leg(lib, L, synth, vpdq):
                 for k in range(frames_per_video):
                     np.copyto(hs.acquire_frame(ch), video[k])
                     hs.commit_frame()
+            elif feed == "acquire_run":
+                k = 0
+                while k < frames_per_video:
+                    run_ = hs.acquire_frames(frames_per_video - k, ch)
+                    np.copyto(run_, video[k:k + run_.shape[0]])
+                    hs.commit_frames()
+                    k += run_.shape[0]
             else:
                 for k in range(frames_per_video):
                     hs.acquire_frame(ch)
                     hs.commit_frame()
             return hs.finish()
 
-        for feed in ("bytes", "buffer", "acquire_copy", "acquire_only"):
-            assert run("acquire_copy" if feed == "acquire_only" else feed).bytes == want  # warm-up, fills the slots
+        nt_level = C.c_int(0)
+        L.check(lib.hvd_debug_get(b"copy_nt", C.byref(nt_level)))
+        res["copy_nt_level"] = {0: "plain memcpy", 2: "AVX2 streaming stores", 3: "AVX-512 streaming stores"}.get(nt_level.value, "?")
+        for feed in ("bytes", "bytes_memcpy", "buffer", "acquire_copy", "acquire_only", "acquire_run"):
+            if feed == "bytes_memcpy":
+                if ch != 3 or nt_level.value == 0:
+                    continue
+                L.check(lib.hvd_debug_set(b"copy_nt", 0))
+            real = "bytes" if feed == "bytes_memcpy" else feed
+            assert run("acquire_copy" if feed == "acquire_only" else real).bytes == want  # warm-up, fills the slots
             t = time.perf_counter()
             for _ in range(n_videos):
-                got = run(feed)
+                got = run(real)
                 assert got.bytes == want, f"VideoHasher({feed}) differs from the batch entry point"
             dt = time.perf_counter() - t
+            if feed == "bytes_memcpy":
+                L.check(lib.hvd_debug_set(b"copy_nt", 1))
             fps = n_videos * frames_per_video / dt
             res[feed] = {"frames_per_s": sig(fps), "GBps": round(fps * fb / 1e9, 2), "h2d_frac": round(fps * fb / 1e9 / h2d, 3),
                          "ms_per_video": round(dt / n_videos * 1e3, 3), "us_per_frame": round(dt / n_videos / frames_per_video * 1e6, 2)}
@@ -312,7 +332,8 @@ def single_process(args) -> int:
 
             traceback.print_exc()
             failed.append((r, repr(exc)))
-            members[r]._s.barrier.abort()
+            members[r].abort()
+            L.group_abort()
 
     ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(1, args.gpus)]
     for t in ts:

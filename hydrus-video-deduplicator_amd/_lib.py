@@ -37,6 +37,8 @@ SIGNATURES = {
     "hvd_set_context": (_int, [_int]),
     "hvd_get_context": (_int, []),
     "hvd_group_exchange": (_int, []),
+    "hvd_group_abort": (_int, []),
+    "hvd_runtime_info": (_int, [C.c_char_p, _sz]),
     "hvd_shutdown": (_int, []),
     "hvd_last_error": (_int, [C.c_char_p, _sz]),
     "hvd_dct_matrix": (_int, [_vp]),
@@ -53,6 +55,8 @@ SIGNATURES = {
     "hvd_hasher_set_threads": (_int, [_vp, _int]),
     "hvd_hasher_acquire": (_int, [_vp, C.POINTER(_vp)]),
     "hvd_hasher_commit": (_int, [_vp]),
+    "hvd_hasher_acquire_n": (_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_i64)]),
+    "hvd_hasher_commit_n": (_int, [_vp, _i64]),
     "hvd_hasher_pending": (_int, [_vp, C.POINTER(_i64)]),
     "hvd_hasher_finish": (_int, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "hvd_hasher_destroy": (_int, [_vp]),
@@ -185,6 +189,20 @@ def set_context(index: int) -> None:
 
 def group_exchange() -> str:
     return {0: "none", 1: "rccl", 2: "host"}[load().hvd_group_exchange()]
+
+
+def group_abort() -> None:
+    """Release the other contexts' threads from an exchange step this thread will never reach (hvd_group_abort)."""
+    load().hvd_group_abort()
+
+
+def runtime_info() -> dict:
+    """HIP / RCCL versions and library paths, the visible devices, the group's peer matrix (hvd_runtime_info)."""
+    import json
+
+    buf = C.create_string_buffer(1 << 16)
+    check(load().hvd_runtime_info(buf, len(buf)))
+    return json.loads(buf.value.decode("utf-8", "replace"))
 
 
 def ensure() -> C.CDLL:

@@ -10,6 +10,7 @@
 // HVD_ERR_STATE / HVD_ERR_NO_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -105,25 +106,55 @@ std::mutex g_mu;
 // Rendezvous of the group's worker threads (one per context) for the exchange steps that have no RCCL underneath: a group
 // that lists one device twice (RCCL refuses duplicate devices; tests/test_gpu_round4.py), where the ranks' candidates and
 // keys meet in host memory instead. A plain generation barrier plus a slot per rank.
+// The barrier can be ABORTED: a rank that leaves a group call with an error -- a HIP failure between two
+// barriers, a context that is not ready -- breaks it (run_on_group), so that its peers come out of their wait with `false`
+// and return an error instead of waiting for ever with the group mutex held. run_on_group re-arms it for the next call.
 struct HostExchange {
     std::mutex mu;
     std::condition_variable cv;
     int arrived = 0;
     unsigned long long gen = 0;
+    bool broken = false;
     std::vector<std::vector<unsigned long long>> words;  // one vector per rank
-    void barrier(int n) {
+    bool barrier(int n) {
         std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
         const unsigned long long my = gen;
         if (++arrived == n) {
             arrived = 0;
             ++gen;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return gen != my; });
+            cv.wait(lk, [&] { return gen != my || broken; });
         }
+        return !broken;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        broken = true;
+        cv.notify_all();
+    }
+    void rearm() {
+        std::lock_guard<std::mutex> lk(mu);
+        broken = false;
+        arrived = 0;
     }
 };
 HostExchange g_hx;
+// every host-memory barrier of a group call: a broken barrier ends the call on this rank too
+#define HX_BARRIER(W)                                                                                              \
+    do {                                                                                                            \
+        if (!g_hx.barrier(W)) return fail(HVD_ERR_RCCL, "group exchange abandoned: another context of the group failed"); \
+    } while (0)
+
+// Declared at the top of every host-memory exchange block: whoever leaves the block early (HIP_TRY, a broken barrier)
+// breaks the barrier for its peers on the way out; the normal exit -- after the block's last barrier -- disarms it.
+struct HxGuard {
+    bool done = false;
+    ~HxGuard() {
+        if (!done) g_hx.abort();
+    }
+};
 
 // pdqhashing.cpp fill_dct_matrix_64_cached: float scale * double cos, rounded once.
 void fill_dct(float* out) {
@@ -328,6 +359,7 @@ int hvd_init_devices(const int* devices, int n_devices) {
     g_nctx = n_devices;
     g_group_rccl = false;
     g_hx.words.assign((size_t)n_devices, {});
+    g_hx.rearm();
     if (n_devices > 1) {
         // The exchange steps of the sharded searches: RCCL all-gathers between the group's devices (ncclCommInitAll: one
         // process, one communicator per device). RCCL refuses a device that is listed twice -- such a group (a test
@@ -427,6 +459,85 @@ int hvd_set_context(int index) {
 int hvd_get_context(void) { return t_ctx; }
 
 int hvd_group_exchange(void) { return g_nctx <= 1 ? 0 : g_group_rccl ? 1 : 2; }
+
+int hvd_group_abort(void) {
+    g_hx.abort();
+    if (g_group_rccl)
+        for (int k = 0; k < g_nctx; ++k)
+            if (g_ctx[k].comm_ready) {
+                g_ctx[k].comm_ready = false;
+                (void)ncclCommAbort(g_ctx[k].comm);
+            }
+    return HVD_OK;
+}
+
+int hvd_runtime_info(char* buf, size_t len) {
+    if (!buf || len == 0) return fail(HVD_ERR_ARG, "buf is NULL");
+    std::string o = "{";
+    auto add = [&](const char* fmt, ...) {
+        char tmp[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(tmp, sizeof tmp, fmt, ap);
+        va_end(ap);
+        o += tmp;
+    };
+    int rt = 0, drv = 0, nccl = 0, ndev = 0;
+    (void)hipRuntimeGetVersion(&rt);
+    (void)hipDriverGetVersion(&drv);
+    (void)ncclGetVersion(&nccl);
+    if (hipGetDeviceCount(&ndev) != hipSuccess) {
+        (void)hipGetLastError();
+        ndev = 0;
+    }
+    Dl_info di;
+    const char* rccl_path = dladdr((void*)&ncclGetVersion, &di) && di.dli_fname ? di.dli_fname : "?";
+    const char* hip_path = dladdr((void*)&hipRuntimeGetVersion, &di) && di.dli_fname ? di.dli_fname : "?";
+    add("\"abi\": %d, \"hip_runtime_version\": %d, \"hip_driver_version\": %d, \"rccl_version\": %d, \"rccl_built_against\": %d, "
+        "\"librccl_path\": \"%s\", \"libamdhip64_path\": \"%s\", \"visible_devices\": %d, \"devices\": [",
+        HVD_ABI_VERSION, rt, drv, nccl, NCCL_VERSION_CODE, rccl_path, hip_path, ndev);
+    for (int d = 0; d < ndev && d < 16; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
+        char bus[32] = "?";
+        (void)hipDeviceGetPCIBusId(bus, sizeof bus, d);
+        add("%s{\"index\": %d, \"name\": \"%s\", \"arch\": \"%s\", \"pci\": \"%s\", \"cus\": %d, \"mem_gib\": %.1f, \"clock_mhz\": %d}",
+            d ? ", " : "", d, p.name, p.gcnArchName, bus, p.multiProcessorCount, (double)p.totalGlobalMem / (1 << 30), p.clockRate / 1000);
+    }
+    o += "], \"group\": [";
+    for (int k = 0; k < g_nctx; ++k) add("%s%d", k ? ", " : "", g_ctx[k].device);
+    add("], \"group_exchange\": \"%s\", \"peers\": [", g_nctx <= 1 ? "none" : g_group_rccl ? "rccl" : "host");
+    // peer matrix of the group's devices (all visible ones if there is no group): access + link type + hops
+    std::vector<int> devs;
+    for (int k = 0; k < g_nctx; ++k) devs.push_back(g_ctx[k].device);
+    if (devs.size() <= 1) {
+        devs.clear();
+        for (int d = 0; d < ndev && d < 16; ++d) devs.push_back(d);
+    }
+    bool first = true;
+    for (size_t a = 0; a < devs.size(); ++a)
+        for (size_t b = 0; b < devs.size(); ++b) {
+            if (devs[a] == devs[b]) continue;
+            int can = 0;
+            uint32_t link = 0, hops = 0;
+            if (hipDeviceCanAccessPeer(&can, devs[a], devs[b]) != hipSuccess) (void)hipGetLastError();
+            if (hipExtGetLinkTypeAndHopCount(devs[a], devs[b], &link, &hops) != hipSuccess) {
+                (void)hipGetLastError();
+                link = 0xFFFFFFFFu;
+            }
+            // hsa_amd_link_info_type_t: 0 HyperTransport, 1 QPI, 2 PCIe, 3 InfiniBand, 4 xGMI
+            const char* lname = link == 4 ? "xgmi" : link == 2 ? "pcie" : link == 0xFFFFFFFFu ? "?" : "other";
+            add("%s{\"from\": %d, \"to\": %d, \"access\": %d, \"link\": \"%s\", \"link_type\": %d, \"hops\": %u}", first ? "" : ", ",
+                devs[a], devs[b], can, lname, (int)link, hops);
+            first = false;
+        }
+    o += "]}";
+    snprintf(buf, len, "%s", o.c_str());
+    return o.size() < len ? HVD_OK : fail(HVD_ERR_OVERFLOW, "runtime info needs %zu bytes", o.size() + 1);
+}
 
 int hvd_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -591,33 +702,45 @@ int hvd_debug_set(const char* key, int value) {
     }
     if (strcmp(key, "vmatch_slots_log2") == 0) {
         if (value != 0 && (value < 4 || value > 30)) return fail(HVD_ERR_ARG, "vmatch_slots_log2: 0 (automatic) or 4..30");
-        g.v_force_slots_log2 = value;
+        for (int k = 0; k < g_nctx; ++k) g_ctx[k].v_force_slots_log2 = value;  // (every context of the group: ADVICE r4)
         return HVD_OK;
     }
     if (strcmp(key, "vmatch_variant") == 0) {  // tests / scripts/gpu_fuzz_k3.py: the video-level searches through one explicit form
         if (value != 0 && (value < 8 || value > 19)) return fail(HVD_ERR_ARG, "vmatch_variant: 0 (default) or an MFMA form 8..19");
-        g.v_variant = value;
+        // every context of the group: forms differ in their tile height, so ranks on different forms would walk different
+        // (rb + cb) % world partitions -- tiles skipped or compared twice
+        for (int k = 0; k < g_nctx; ++k) g_ctx[k].v_variant = value;
         return HVD_OK;
     }
-    if (strcmp(key, "vmatch_fail_rank") == 0) {  // tests: rank (value - 1) fails before the key exchange; 0 = off
-        g.v_fail_rank = value;
+#ifndef HVD_NO_BENCH_SYMBOLS
+    if (strcmp(key, "vmatch_fail_rank") == 0) {  // tests only (include/hvd_mi355x_bench.h): rank (value - 1) fails before the key exchange; 0 = off
+        for (int k = 0; k < g_nctx; ++k) g_ctx[k].v_fail_rank = value;
         return HVD_OK;
     }
+#endif
     if (strcmp(key, "vmatch_exchange") == 0) {
         if (value < 0 || value > 2) return fail(HVD_ERR_ARG, "vmatch_exchange: 0 iff world > 1, 1 always, 2 never (partial results)");
-        g.v_exchange_mode = value;
+        for (int k = 0; k < g_nctx; ++k) g_ctx[k].v_exchange_mode = value;
         return HVD_OK;
     }
     if (strcmp(key, "pdq_fused_down512") == 0) {
         hvd::g_pdq_fused_down512 = value != 0;
         return HVD_OK;
     }
+    if (strcmp(key, "copy_nt") == 0) {  // hvd_hasher_push: non-temporal stores into the pinned ring (1, default where the CPU has them) or plain memcpy (0)
+        hvd::stream_set_copy_nt(value);
+        return HVD_OK;
+    }
     return fail(HVD_ERR_ARG, "unknown debug key %s", key);
 }
 
 int hvd_debug_get(const char* key, int* out_value) {
-    if (int rc = need_ready()) return rc;
     if (!key || !out_value) return fail(HVD_ERR_ARG, "NULL argument");
+    if (strcmp(key, "copy_nt") == 0) {  // (host only: no device needed)
+        *out_value = hvd::stream_copy_nt_level();
+        return HVD_OK;
+    }
+    if (int rc = need_ready()) return rc;
     // what the probe of the last auto-variant launch saw and chose: form id, survivors over bits 0..127 / 128..255,
     // 1 if the first stage ran on bits 128..255
     const char* keys[4] = {"mfma_auto_form", "mfma_probe_survivors", "mfma_probe_survivors_hi", "mfma_auto_half"};
@@ -831,13 +954,32 @@ int run_on_group(const std::function<int(int)>& fn) {
     const int n = g_nctx;
     if (n <= 1) return fn(0);
     std::lock_guard<std::mutex> lk(g_group_mu);
+    g_hx.rearm();
     std::vector<int> rc((size_t)n, HVD_OK);
     std::vector<std::string> msg((size_t)n);
+    std::once_flag rccl_abort;
     auto body = [&](int i) {
         t_ctx = i;
         rc[(size_t)i] = need_ready();
         if (rc[(size_t)i] == HVD_OK) rc[(size_t)i] = fn(i);
-        if (rc[(size_t)i] != HVD_OK) msg[(size_t)i] = g_err;
+        if (rc[(size_t)i] != HVD_OK) {
+            msg[(size_t)i] = g_err;
+            // A rank that leaves with an error may leave peers waiting for it in an exchange step. Host-memory
+            // group: break the barrier. RCCL group: a HARD failure (HIP / RCCL / state -- not the overflow and argument
+            // verdicts, which every rank reaches together after the exchange) aborts the group's communicators, which
+            // releases a peer blocked in a collective on the device; the group then has no exchange until it is
+            // initialised again (every later sharded call fails loudly instead of hanging).
+            g_hx.abort();
+            const int code = rc[(size_t)i];
+            if (g_group_rccl && (code == HVD_ERR_HIP || code == HVD_ERR_RCCL || code == HVD_ERR_STATE))
+                std::call_once(rccl_abort, [&] {
+                    for (int k = 0; k < n; ++k)
+                        if (g_ctx[k].comm_ready) {
+                            g_ctx[k].comm_ready = false;
+                            (void)ncclCommAbort(g_ctx[k].comm);
+                        }
+                });
+        }
     };
     std::vector<std::thread> th;
     for (int i = 1; i < n; ++i) th.emplace_back(body, i);
@@ -859,13 +1001,15 @@ int exchange_words(const unsigned long long word[2], std::vector<unsigned long l
     const int W = g.world;
     all.assign(2 * (size_t)W, 0ull);
     if (g.host_exchange) {
-        g_hx.barrier(W);
+        HxGuard hx;
+        HX_BARRIER(W);
         g_hx.words[(size_t)g.rank].assign(word, word + 2);
-        g_hx.barrier(W);
+        HX_BARRIER(W);
         for (int r = 0; r < W; ++r) {
             all[2 * (size_t)r] = g_hx.words[(size_t)r][0];
             all[2 * (size_t)r + 1] = g_hx.words[(size_t)r][1];
         }
+        hx.done = true;
         return HVD_OK;
     }
     if (!g.comm_ready) return fail(HVD_ERR_STATE, "no communicator on context %d", g.id);
@@ -1207,7 +1351,9 @@ int vmatch_build(const VmArgs& v) {
     const unsigned long long frames = (unsigned long long)v.nt + (v.rect ? v.nq : 0u);
     slots = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * frames));
     if (g.v_force_slots_log2) slots = 1ull << g.v_force_slots_log2;
+#ifndef HVD_NO_BENCH_SYMBOLS
     if (g.v_fail_rank == v.rank + 1) return fail(HVD_ERR_HIP, "injected failure on rank %d (hvd_debug_set vmatch_fail_rank)", v.rank);
+#endif
     for (;;) {
         SCR(S_SET, 8 * slots, d_set);
         HIP_TRY(hipMemsetAsync(d_set, 0xFF, 8 * slots, g.stream));
@@ -1249,14 +1395,17 @@ int vmatch_build(const VmArgs& v) {
         std::vector<unsigned long long> words(2 * (size_t)W);
         auto agree = [&](const char* what, int own_rc) -> int {  // all-gather (count, status); a failure anywhere -> everyone leaves
             if (g.host_exchange) {  // group without RCCL: the words meet in host memory
-                g_hx.barrier(W);    // (everybody is done with the previous round's slots)
+                HxGuard hx;
+                HX_BARRIER(W);      // (everybody is done with the previous round's slots)
                 g_hx.words[(size_t)g.rank].assign(word, word + 2);
-                g_hx.barrier(W);
+                HX_BARRIER(W);
                 for (int r = 0; r < W; ++r) {
                     words[2 * (size_t)r] = g_hx.words[(size_t)r][0];
                     words[2 * (size_t)r + 1] = g_hx.words[(size_t)r][1];
                 }
+                hx.done = true;
             } else {
+                if (!g.comm_ready) return fail(HVD_ERR_STATE, "no communicator on context %d (aborted after another rank's failure?)", g.id);
                 HIP_TRY(hipMemcpyAsync(g.x_cnt_in, word, 16, hipMemcpyHostToDevice, g.stream));
                 NCCL_TRY(ncclAllGather(g.x_cnt_in, g.x_cnt_all, 2, ncclUint64, g.comm, g.stream));
                 HIP_TRY(hipMemcpyAsync(words.data(), g.x_cnt_all, 16 * (size_t)W, hipMemcpyDeviceToHost, g.stream));
@@ -1289,16 +1438,19 @@ int vmatch_build(const VmArgs& v) {
         HIP_TRY(hvd::launch_set_to_list(d_set, slots, d_list, mx, d_counters + 2, g.stream));
         if (g.host_exchange) {  // every rank's list through host memory, the concatenation back to every device
             std::vector<unsigned long long>& mine = g_hx.words[(size_t)g.rank];
-            g_hx.barrier(W);
+            HxGuard hx;  // (a failure between the barriers must not strand the peers: ADVICE r4)
+            HX_BARRIER(W);
             mine.resize((size_t)mx);
             HIP_TRY(hipMemcpyAsync(mine.data(), d_list, 8 * (size_t)mx, hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipStreamSynchronize(g.stream));
-            g_hx.barrier(W);
+            HX_BARRIER(W);
             for (int r = 0; r < W; ++r)
                 HIP_TRY(hipMemcpyAsync(d_all + (size_t)r * mx, g_hx.words[(size_t)r].data(), 8 * (size_t)mx, hipMemcpyHostToDevice, g.stream));
             HIP_TRY(hipStreamSynchronize(g.stream));
-            g_hx.barrier(W);  // (the slots are free again only when everybody has copied them)
+            HX_BARRIER(W);  // (the slots are free again only when everybody has copied them)
+            hx.done = true;
         } else {
+            if (!g.comm_ready) return fail(HVD_ERR_STATE, "no communicator on context %d (aborted after another rank's failure?)", g.id);
             NCCL_TRY(ncclAllGather(d_list, d_all, 8 * mx, ncclUint8, g.comm, g.stream));
         }
         unsigned long long slots2 = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * total));
@@ -1717,16 +1869,18 @@ int hvd_comm_allgather_bytes(const void* d_send, void* d_recv, size_t bytes_per_
     if (g.host_exchange) {  // in-process group without RCCL: through host memory (every context's thread calls this)
         const int W = g.world;
         std::vector<unsigned long long>& mine = g_hx.words[(size_t)g.rank];
-        g_hx.barrier(W);
+        HxGuard hx;
+        HX_BARRIER(W);
         mine.resize((bytes_per_rank + 7) / 8);
         if (bytes_per_rank) HIP_TRY(hipMemcpyAsync(mine.data(), d_send, bytes_per_rank, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        g_hx.barrier(W);
+        HX_BARRIER(W);
         for (int r = 0; r < W && bytes_per_rank; ++r)
             HIP_TRY(hipMemcpyAsync((char*)d_recv + (size_t)r * bytes_per_rank, g_hx.words[(size_t)r].data(), bytes_per_rank,
                                    hipMemcpyHostToDevice, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        g_hx.barrier(W);
+        HX_BARRIER(W);
+        hx.done = true;
         return HVD_OK;
     }
     if (!g.comm_ready) return fail(HVD_ERR_STATE, "hvd_comm_init() has not been called");
@@ -1752,11 +1906,12 @@ int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_h
     if (g.host_exchange) {  // in-process group without RCCL: the ranks' records meet in host memory
         const int W = g.world;
         std::vector<unsigned long long>& mine = g_hx.words[(size_t)g.rank];
-        g_hx.barrier(W);
+        HxGuard hx;
+        HX_BARRIER(W);
         mine.resize(2 * (size_t)count);
         if (count) HIP_TRY(hipMemcpyAsync(mine.data(), d_pairs, sizeof(hvd_pair) * (size_t)count, hipMemcpyDeviceToHost, g.stream));
         HIP_TRY(hipStreamSynchronize(g.stream));
-        g_hx.barrier(W);
+        HX_BARRIER(W);
         size_t total = 0;
         for (int r = 0; r < W; ++r) total += g_hx.words[(size_t)r].size() / 2;
         *out_total = (int64_t)total;
@@ -1771,7 +1926,8 @@ int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_h
                 o += m;
             }
         }
-        g_hx.barrier(W);
+        HX_BARRIER(W);
+        hx.done = true;  // (an overflow is this rank's own verdict after the exchange: every barrier has been passed)
         return rc;
     }
     if (!g.comm_ready) return fail(HVD_ERR_STATE, "hvd_comm_init() has not been called");

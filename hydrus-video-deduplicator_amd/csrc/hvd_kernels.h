@@ -44,6 +44,8 @@ hipError_t mfma_select_buffer(int ctx_id, uint32_t** out);  // per context; [0] 
 void mfma_release();
 void pdq_release();           // k_pdq.hip: free the hash kernel's work-counter ring (hvd_shutdown)
 void stream_release_cache();  // hvd_stream.cpp: free the parked hasher slot sets (hvd_shutdown)
+void stream_set_copy_nt(int on);  // hvd_stream.cpp / copy_pool.h: non-temporal stores into the pinned ring (debug key "copy_nt")
+int stream_copy_nt_level();
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 
 // Video-level reduction and quality compaction (k_vmatch.hip).

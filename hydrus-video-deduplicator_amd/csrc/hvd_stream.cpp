@@ -142,6 +142,8 @@ void free_hasher(hvd_hasher* hs) {
 }  // namespace
 
 namespace hvd {
+void stream_set_copy_nt(int on) { set_copy_nt(on); }   // hvd_debug_set("copy_nt", 0|1)
+int stream_copy_nt_level() { return copy_nt_level(); }  // hvd_debug_get("copy_nt"): 0 plain memcpy, 2 AVX2, 3 AVX-512 streaming stores
 void stream_release_cache() {
     g_copy_pool.stop();
     std::lock_guard<std::mutex> lk(g_park_mu);
@@ -254,6 +256,35 @@ int hvd_hasher_commit(hvd_hasher* hs) {
     hs->acquired = false;
     Slot& s = hs->slot[hs->cur];
     if (++s.filled == hs->batch) {
+        if (int rc = submit(hs, s)) return rc;
+        hs->cur = (hs->cur + 1) % kSlots;
+    }
+    return HVD_OK;
+}
+
+/* The same for a RUN of frames (ABI 5): *out_frames is where the next frames belong, *out_n (1 <= *out_n <= want) how many
+ * fit there back to back -- what is left of the current batch slot. One call, one pointer, k frames: a decoder that fills
+ * 64x64 frames pays one FFI round trip per run instead of two per frame. hvd_hasher_commit_n(n) makes the
+ * first n of them count (n <= *out_n; n = 0 is legal and gives the run back). */
+int hvd_hasher_acquire_n(hvd_hasher* hs, int64_t want, uint8_t** out_frames, int64_t* out_n) {
+    if (!hs || !out_frames || !out_n) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/out_frames/out_n");
+    if (want < 1) return hvd::api_fail(HVD_ERR_ARG, "want must be at least 1");
+    if (int rc = hvd_hasher_acquire(hs, out_frames)) return rc;
+    const Slot& s = hs->slot[hs->cur];
+    *out_n = std::min<int64_t>(want, hs->batch - s.filled);
+    return HVD_OK;
+}
+
+int hvd_hasher_commit_n(hvd_hasher* hs, int64_t n) {
+    if (!hs) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher");
+    CtxScope scope(hs->ctx);
+    if (!hs->acquired) return hvd::api_fail(HVD_ERR_STATE, "hvd_hasher_commit_n() without hvd_hasher_acquire_n()");
+    Slot& s = hs->slot[hs->cur];
+    if (n < 0 || n > hs->batch - s.filled) return hvd::api_fail(HVD_ERR_ARG, "commit of %lld frames, %lld acquired at most", (long long)n, (long long)(hs->batch - s.filled));
+    if (int rc = hvd::api_bind_device()) return rc;
+    hs->acquired = false;
+    s.filled += n;
+    if (s.filled == hs->batch) {
         if (int rc = submit(hs, s)) return rc;
         hs->cur = (hs->cur + 1) % kSlots;
     }

@@ -28,6 +28,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// HVD_K2_QABL=<n> builds are timing-only ABLATIONS that produce WRONG RESULTS (survivors counted but not pushed, entries
+// dropped, ...); HVD_K2_QSTATS adds counters to the hot loop. Neither may come out of the product source with a single -D:
+#if (defined(HVD_K2_QABL) || defined(HVD_K2_QSTATS)) && !defined(HVD_DEV_ABLATION)
+#error "HVD_K2_QABL / HVD_K2_QSTATS are developer ablation builds (wrong results): add -DHVD_DEV_ABLATION to confirm"
+#endif
+
 #include <mutex>
 
 #include "hvd_devhash.h"
@@ -396,7 +402,11 @@ constexpr uint32_t kQDrainAt = HVD_K2_QDRAIN_AT;   // settle when the workgroup 
 // or16_groups) | (first row of the tile, relative to the WAVE's first row: 32 t) << 16 (the wave is the queue's index);
 // y = column (absolute) << 1 | h (the lane's half: its rows start 4 h below the tile's first) -- hence n_pad < 2^31
 __shared__ uint2 g_wave_queue[kQEntries];  // wave w's queue: [w * qcap, (w + 1) * qcap), qcap = kQEntries / waves
-__shared__ __attribute__((aligned(16))) uint32_t g_wave_qn[kQMaxWaves];
+// Two sets of fill levels, used in turn: the words settle() of super-panel k reads behind its barrier are not the
+// words publish() of super-panel k+1 writes, so a wave that is late to read can never see a sibling's NEWER level and come to
+// a different drain decision (divergent barriers); the set of super-panel k is written again only by k+2, and the barrier of
+// k+1 lies in between.
+__shared__ __attribute__((aligned(16))) uint32_t g_wave_qn[2][kQMaxWaves];
 
 __device__ __forceinline__ uint32_t sign_popc(const uint4& x, const uint4& y, uint32_t acc) {
     // FP4 images: equal magnitude bits cancel, only sign nibbles survive the XOR (rows beyond n are FP4 zeros -- filtered
@@ -441,8 +451,8 @@ __device__ __forceinline__ void settle_pair(const HitCtx& c, uint32_t i, uint32_
 struct QCounts {
     uint32_t pre[kQMaxWaves + 1];
 };
-__device__ __forceinline__ QCounts load_qcounts(uint32_t waves) {
-    const uint4 lo = *reinterpret_cast<const uint4*>(&g_wave_qn[0]), hi = *reinterpret_cast<const uint4*>(&g_wave_qn[4]);
+__device__ __forceinline__ QCounts load_qcounts(uint32_t waves, uint32_t par) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(&g_wave_qn[par][0]), hi = *reinterpret_cast<const uint4*>(&g_wave_qn[par][4]);
     const uint32_t raw[kQMaxWaves] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     QCounts c;
     uint32_t run = 0;
@@ -502,8 +512,8 @@ __device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx,
     const uint32_t geom = geom_v, row0 = row0_v, ohw = other_half_v;
     const HitCtx* cc = ctx;
 #endif
-    const uint32_t waves = geom & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;  // waves | tiles << 4 | entries per wave << 8
-    const QCounts qc = load_qcounts(waves);
+    const uint32_t waves = geom & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;  // waves | tiles << 4 | entries per wave << 8 | marks per tile << 20 | set of fill levels << 24
+    const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
     const uint32_t total = qc.pre[kQMaxWaves];
     const uint4* __restrict__ db_q = cc->db_q;
     const uint4* __restrict__ db_t = cc->db_t;
@@ -577,7 +587,7 @@ __device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, ui
 #endif
     const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
     const uint32_t waves = geom & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;
-    const QCounts qc = load_qcounts(waves);
+    const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
     const HitCtx c = load_ctx(ctx);
     const uint32_t total = qc.pre[kQMaxWaves];
     const bool packed = c.db_t != nullptr;
@@ -663,9 +673,9 @@ __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict_
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
     const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
     const auto* cc = (const __attribute__((address_space(4))) HitCtx*)uniform_u64((unsigned long long)ctx);
-    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = geom >> 20, nthreads = 64u * waves;
+    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = (geom >> 20) & 7u, nthreads = 64u * waves;
     const uint32_t qshift = qg >> 1, chunks = 4u >> qshift, top = tiles * qg - 1u;  // qg = 1, 2, 4 -> shift 0, 1, 2; 4-row chunks per mark
-    const QCounts qc = load_qcounts(waves);
+    const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
     const uint32_t total = qc.pre[kQMaxWaves];
     const uint4* __restrict__ db_q = cc->db_q;
     const uint4* __restrict__ db_t = cc->db_t;
@@ -769,9 +779,9 @@ __device__ __noinline__ void settle_marked_panel_wg(const HitCtx* __restrict__ c
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
     const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
     const uint32_t oh = ohw & 1u, wrows = ohw >> 8;
-    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = geom >> 20, nthreads = 64u * waves;
+    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = (geom >> 20) & 7u, nthreads = 64u * waves;
     const uint32_t qshift = qg >> 1, nrows = 16u >> qshift, top = tiles * qg - 1u;
-    const QCounts qc = load_qcounts(waves);
+    const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
     const HitCtx c = load_ctx(ctx);
     const uint32_t total = qc.pre[kQMaxWaves];
     const bool packed = c.db_t != nullptr;
@@ -1115,17 +1125,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
     // QUEUE: every wave publishes its fill level in front of a super-panel barrier; behind it the workgroup decides -- on
     // the same four numbers -- whether to settle the queues now (drain_queues_wg).
     const uint32_t drain_at = kQDrainAt;
-    auto publish = [&]() {
+    auto publish = [&](const uint32_t par) {
         if constexpr (QUEUE) {
-            if (lane == 0u) g_wave_qn[wave] = qidx - wave * QCAP;
+            if (lane == 0u) g_wave_qn[par][wave] = qidx - wave * QCAP;
         }
     };
-    auto settle = [&](const bool final, uint4* free_panel) {
+    auto settle = [&](const bool final, uint4* free_panel, const uint32_t par) {
 #if defined(HVD_K2_QABL) && HVD_K2_QABL == 10  // timing-only ablation: (with nothing pushed) no look at the fill levels either
         return;
 #endif
         if constexpr (QUEUE) {
-            const QCounts qc = load_qcounts(WAVES);
+            const QCounts qc = load_qcounts(WAVES, par);
             const uint32_t sum = qc.pre[kQMaxWaves];
             uint32_t mx = 0;
 #pragma unroll
@@ -1141,7 +1151,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
                 }
 #endif
 #if !(defined(HVD_K2_QABL) && HVD_K2_QABL == 3)  // 3 = pushed entries are dropped instead of settled
-                constexpr uint32_t GEOM = (uint32_t)WAVES | ((uint32_t)TILES << 4) | (QCAP << 8) | ((uint32_t)QG << 20);
+                const uint32_t GEOM = (uint32_t)WAVES | ((uint32_t)TILES << 4) | (QCAP << 8) | ((uint32_t)QG << 20) | (par << 24);
                 if constexpr (QUEUE >= 2) {
                     const uint32_t left = drain_filter_panel_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
                     if (__builtin_expect(__any(left != 0u), 0)) settle_marked_panel_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
@@ -1164,17 +1174,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
         // lds1 was last read in iteration sp-1, which every wave left through a barrier
         if (sp + 1u < nsp) stage_super_panel<WAVES>(img + (size_t)(jsp + kSuper) * 8u, lds1, wave, lane);
         process(lds0, jsp);
-        publish();
+        publish(0u);
         __syncthreads();  // (drains the in-flight global->LDS loads with vmcnt(0) first)
         if (sp + 1u >= nsp) break;
-        settle(false, lds0);  // (lds0 has just been used up and is not refilled before the settlement is over)
+        settle(false, lds0, 0u);  // (lds0 has just been used up and is not refilled before the settlement is over)
         if (sp + 2u < nsp) stage_super_panel<WAVES>(img + (size_t)(jsp + 2u * kSuper) * 8u, lds0, wave, lane);
         process(lds1, jsp + kSuper);
-        publish();
+        publish(1u);
         __syncthreads();
-        if (sp + 2u < nsp) settle(false, lds1);
+        if (sp + 2u < nsp) settle(false, lds1, 1u);
     }
-    settle(true, lds0);  // (nothing is in flight any more: both buffers are free)
+    // the last super-panel's levels: set 0 if their number is odd (nsp >= 1: the tile holds columns beyond its first row)
+    settle(true, lds0, (nsp & 1u) ^ 1u);  // (nothing is in flight any more: both buffers are free)
     // every path leaves the loop through a barrier: all hits of this workgroup are in LDS now
     flush_pairs_wg(ctx, wave * 64u + lane, NT);
 }

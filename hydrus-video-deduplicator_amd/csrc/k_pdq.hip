@@ -22,6 +22,12 @@
 //   median   radix select of the 128th smallest of 256 keys with wave ballots
 //   bits     ballot(B > median): lane l, output r is hash bit l + 64 r
 #include <hip/hip_runtime.h>
+
+// HVD_ABL_NOSTATE / HVD_ABL_NOFETCH / HVD_ABL_DMAFETCH builds are timing-only ABLATIONS of the down-sampler that produce
+// WRONG RESULTS. They may not come out of the product source with a single -D:
+#if (defined(HVD_ABL_NOSTATE) || defined(HVD_ABL_NOFETCH) || defined(HVD_ABL_DMAFETCH)) && !defined(HVD_DEV_ABLATION)
+#error "HVD_ABL_* are developer ablation builds (wrong results): add -DHVD_DEV_ABLATION to confirm"
+#endif
 #include <stdint.h>
 #include <string.h>
 

@@ -135,6 +135,12 @@ def run_on_contexts(fn, world: int | None = None) -> list:
             out[r] = fn(r, world)
         except BaseException as exc:  # noqa: BLE001 - re-raised below
             err[r] = exc
+            # the other ranks may be waiting for this one in an exchange step it will never reach: break the
+            # group's barrier / abort its communicators, so that they fail instead of blocking join() for ever
+            try:
+                _lib.group_abort()
+            except Exception:  # noqa: BLE001 - the original exception is what gets reported
+                pass
 
     ts = [threading.Thread(target=body, args=(r,)) for r in range(1, world)]
     for t in ts:
@@ -143,7 +149,8 @@ def run_on_contexts(fn, world: int | None = None) -> list:
     for t in ts:
         t.join()
     _lib.set_context(0)
-    for e in err:
+    first = next((e for e in err if e is not None and not (isinstance(e, _lib.HvdError) and "abandoned" in str(e))), None)
+    for e in ([first] if first is not None else err):  # (the rank that failed first, not a peer it released)
         if e is not None:
             raise e
     return out

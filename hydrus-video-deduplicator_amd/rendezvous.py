@@ -223,7 +223,9 @@ class ThreadRendezvous:
         def __init__(self, world: int):
             self.world = world
             self.slots = [None] * world
-            self.barrier = threading.Barrier(world)
+            # every wait is bounded (HVD_RDZV_TIMEOUT seconds, default 900): a rank that died before a collective turns into
+            # threading.BrokenBarrierError on the others instead of a join() that never returns
+            self.barrier = threading.Barrier(world, timeout=float(os.environ.get("HVD_RDZV_TIMEOUT", "900")))
 
     def __init__(self, rank: int, shared: "ThreadRendezvous._Shared"):
         self.rank, self.world, self._s = rank, shared.world, shared
@@ -243,6 +245,11 @@ class ThreadRendezvous:
 
     def barrier(self) -> None:
         self._s.barrier.wait()
+
+    def abort(self) -> None:
+        """A rank that fails calls this on its way out: every rank waiting in (or arriving at) a collective of this group
+        gets threading.BrokenBarrierError."""
+        self._s.barrier.abort()
 
     def broadcast(self, data: bytes | None, src: int = 0) -> bytes:
         return self.allgather(data if self.rank == src else b"")[src]

@@ -164,6 +164,9 @@ class VideoHasher:
         self._channels = 0
         self._handle = None
         self._finished = False
+        self._run = None        # acquire_frame(): view of the run of frames acquired from the native hasher ...
+        self._run_pos = 0       # ... and how many of them commit_frame() has counted
+        self._batch_run = None  # acquire_frames(): the run handed out
         self._lib = _lib.ensure()  # fail at construction, not at the first frame, if no GPU is usable
 
     def _open(self, channels: int) -> None:
@@ -180,28 +183,75 @@ class VideoHasher:
             nt = max(1, (os.cpu_count() or 1) + nt)
         _lib.check(self._lib.hvd_hasher_set_threads(h, nt))
 
-    def acquire_frame(self, channels: int = 3) -> np.ndarray:
-        """Zero-copy feed (hvd_hasher_acquire): a writable uint8 view of the pinned slot memory for the NEXT
-        frame -- shape (height, width, 3) or (height, width) -- so that a decoder can reformat straight into
-        it (e.g. ``frame.to_ndarray(...)`` with ``out=``, or ``np.copyto``); ``commit_frame()`` makes it count.
-        Blocks like ``hash_frame`` when every batch slot is in flight."""
+    def _check_feed(self, channels: int) -> None:
         if self._finished:
-            raise RuntimeError("acquire_frame() after finish()")
+            raise RuntimeError("frame fed after finish()")
         if channels not in (1, 3):
             raise ValueError("channels must be 1 (gray) or 3 (rgb24)")
         if self._handle is None:
             self._open(channels)
         elif channels != self._channels:
             raise ValueError("all frames of one video must have the same pixel format")
-        p = C.c_void_p()
-        _lib.check(self._lib.hvd_hasher_acquire(self._handle, C.byref(p)))
-        nbytes = self._frame_bytes_rgb if channels == 3 else self._frame_bytes_gray
-        buf = (C.c_uint8 * nbytes).from_address(p.value)
-        shape = (self.height, self.width, 3) if channels == 3 else (self.height, self.width)
+
+    def _acquire_run(self, want: int) -> np.ndarray:
+        """hvd_hasher_acquire_n: one view [got, h, w(, 3)] over the next `got` <= want frames of the pinned slot."""
+        p, got = C.c_void_p(), C.c_int64(0)
+        _lib.check(self._lib.hvd_hasher_acquire_n(self._handle, int(want), C.byref(p), C.byref(got)))
+        ch = self._channels
+        fb = self._frame_bytes_rgb if ch == 3 else self._frame_bytes_gray
+        buf = (C.c_uint8 * (fb * got.value)).from_address(p.value)
+        shape = (got.value, self.height, self.width, 3) if ch == 3 else (got.value, self.height, self.width)
         return np.frombuffer(buf, dtype=np.uint8).reshape(shape)
 
+    def _flush_run(self) -> None:
+        """Hand the frames committed one by one (commit_frame) to the native hasher: one hvd_hasher_commit_n per run."""
+        if self._run is not None:
+            n, self._run = self._run_pos, None
+            self._run_pos = 0
+            _lib.check(self._lib.hvd_hasher_commit_n(self._handle, n))
+
+    def acquire_frames(self, k: int, channels: int = 3) -> np.ndarray:
+        """Zero-copy feed for a RUN of frames (hvd_hasher_acquire_n): a writable uint8 view ``[got, height, width(, 3)]``
+        of the pinned slot memory for the next frames, ``1 <= got <= k`` (what is left of the current batch slot, so a
+        caller loops until its frames are placed); ``commit_frames(n)`` makes the first n count. One FFI round trip per
+        run: a decoder of small frames (64x64) fills hundreds of frames per call. Blocks like ``hash_frame`` when every
+        batch slot is in flight (vpdqpy/vpdqpy.py:115-117)."""
+        if k < 1:
+            raise ValueError("k must be at least 1")
+        self._check_feed(channels)
+        self._flush_run()
+        self._batch_run = self._acquire_run(k)
+        return self._batch_run
+
+    def commit_frames(self, n: int | None = None) -> None:
+        """The first n frames of the run ``acquire_frames`` handed out are complete (default: all of them)."""
+        if self._batch_run is None:
+            raise RuntimeError("commit_frames() without acquire_frames()")
+        n = self._batch_run.shape[0] if n is None else int(n)
+        self._batch_run = None
+        _lib.check(self._lib.hvd_hasher_commit_n(self._handle, n))
+
+    def acquire_frame(self, channels: int = 3) -> np.ndarray:
+        """Zero-copy feed (hvd_hasher_acquire_n underneath): a writable uint8 view of the pinned slot memory for the NEXT
+        frame -- shape (height, width, 3) or (height, width) -- so that a decoder can reformat straight into
+        it (e.g. ``frame.to_ndarray(...)`` with ``out=``, or ``np.copyto``); ``commit_frame()`` makes it count.
+        Blocks like ``hash_frame`` when every batch slot is in flight. The frames of one batch slot are handed out from ONE
+        native call and committed with one (round 5: two ctypes calls and a buffer object per frame made this feed slower
+        than ``hash_frame(bytes)`` for 64x64 frames)."""
+        if self._run is None or self._run_pos == self._run.shape[0]:
+            self._check_feed(channels)
+            self._flush_run()
+            self._run = self._acquire_run(1 << 30)  # the rest of the current batch slot
+        elif channels != self._channels:
+            raise ValueError("all frames of one video must have the same pixel format")
+        return self._run[self._run_pos]
+
     def commit_frame(self) -> None:
-        _lib.check(self._lib.hvd_hasher_commit(self._handle))
+        if self._run is None:
+            raise RuntimeError("commit_frame() without acquire_frame()")
+        self._run_pos += 1
+        if self._run_pos == self._run.shape[0]:
+            self._flush_run()  # the batch slot is full: submitted (H2D + kernels) by the native side
 
     def hash_frame(self, frame) -> None:
         """frame: packed RGB24 bytes (width*height*3, what bytes(frame.planes[0]) yields at
@@ -224,6 +274,8 @@ class VideoHasher:
             self._open(ch)
         elif ch != self._channels:
             raise ValueError("all frames of one video must have the same pixel format")
+        if self._run is not None:
+            self._flush_run()
         _lib.check(self._lib.hvd_hasher_push(self._handle, ptr))
         del keep
 
@@ -232,6 +284,8 @@ class VideoHasher:
         if self._handle is None:
             return VpdqHash(b"")
         try:
+            self._flush_run()
+            self._batch_run = None
             pending = C.c_int64(0)
             _lib.check(self._lib.hvd_hasher_pending(self._handle, C.byref(pending)))
             n = pending.value

@@ -39,7 +39,7 @@ extern "C" {
 
 #define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
 #define HVD_UNIQUE_ID_BYTES 128
-#define HVD_ABI_VERSION 4 /* 4 (round 4): + hvd_init_devices, hvd_context_count, hvd_set_context, hvd_get_context, hvd_group_exchange; 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
+#define HVD_ABI_VERSION 5 /* 5 (round 5): + hvd_hasher_acquire_n, hvd_hasher_commit_n, hvd_group_abort, hvd_runtime_info; 4 (round 4): + hvd_init_devices, hvd_context_count, hvd_set_context, hvd_get_context, hvd_group_exchange; 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
 /* All-pairs kernel the host entry points use: FP4-MFMA with a 128-bit first stage; which of its two forms runs
  * (survivors fetch their other half | second stage out of registers) is chosen per launch from a probe of the data. */
 #define HVD_DEFAULT_VARIANT 13
@@ -78,6 +78,18 @@ int hvd_context_count(int* out_n);  /* contexts of the group (1 after hvd_init, 
 int hvd_set_context(int index);     /* the calling thread's current context (and HIP device) from now on */
 int hvd_get_context(void);
 int hvd_group_exchange(void);       /* 0: no group (one context); 1: RCCL between the devices; 2: host memory */
+/* A caller that drives the contexts from its own threads (one per context) and fails on ONE of them before that thread
+ * reaches an exchange step calls this so that the others do not wait for it for ever: the host-memory barrier is broken
+ * (waiters return HVD_ERR_RCCL), RCCL communicators of the group are aborted (ncclCommAbort releases a collective that is
+ * already waiting on the device). The group has no exchange afterwards until hvd_init_devices() forms it again; the
+ * library does the same by itself when one context of a host-buffer call fails. */
+int hvd_group_abort(void);
+/* What this process runs on, as one JSON object in buf (NUL-terminated, truncated to len): HIP runtime / driver versions,
+ * RCCL version and the path of the librccl that is actually loaded, every visible device (name, PCI bus id, gcnArch, CUs,
+ * memory) and the peer matrix of the group's devices (hipDeviceCanAccessPeer, link type and hop count from
+ * hipExtGetLinkTypeAndHopCount: xGMI or PCIe). bench.py prints it with every measurement so that a multi-GPU run can be
+ * read without access to the box. Callable before hvd_init. */
+int hvd_runtime_info(char* buf, size_t len);
 int hvd_shutdown(void);
 /* Copies the calling thread's last error message (NUL-terminated) into buf. */
 int hvd_last_error(char* buf, size_t len);
@@ -152,6 +164,11 @@ int hvd_hasher_set_threads(hvd_hasher* hs, int n);
  * acquire blocks like push; push == acquire + memcpy + commit. */
 int hvd_hasher_acquire(hvd_hasher* hs, uint8_t** out_frame);
 int hvd_hasher_commit(hvd_hasher* hs);
+/* The same for a run of frames: *out_frames is where the next frames belong, back to back, *out_n (1 <= *out_n <= want)
+ * how many fit there (what is left of the current batch slot); hvd_hasher_commit_n(n) makes the first n count
+ * (0 <= n <= *out_n). One FFI round trip per run instead of two per frame: what a decoder of small frames wants. */
+int hvd_hasher_acquire_n(hvd_hasher* hs, int64_t want, uint8_t** out_frames, int64_t* out_n);
+int hvd_hasher_commit_n(hvd_hasher* hs, int64_t n);
 int hvd_hasher_pending(hvd_hasher* hs, int64_t* out_frames);
 /* All hashes (n*32 bytes) and qualities in push order; the hasher is reusable afterwards. */
 int hvd_hasher_finish(hvd_hasher* hs, uint8_t* out_hashes, int32_t* out_quality, int64_t cap, int64_t* out_n);

@@ -23,6 +23,11 @@ int hvd_dev_synth_video_frames(void* d_frames, int64_t v0, int64_t n_videos, int
  * several threads with different thread counts (the generation race of round 3's pool needed exactly that). */
 int hvd_debug_parallel_copy(void* dst, const void* src, size_t n, int threads);
 
+/* Fault injection, tests only: hvd_debug_set("vmatch_fail_rank", r + 1) makes rank r of the next video-level search fail
+ * before the key exchange, so that the agreement step (every rank leaves the collective with the same error instead of
+ * hanging) can be tested; 0 = off. Like the two entry points above it is absent from -DHVD_NO_BENCH_SYMBOLS builds (the
+ * key is then unknown: HVD_ERR_ARG), and it is deliberately NOT in the key list of hvd_mi355x.h. */
+
 #ifdef __cplusplus
 }
 #endif

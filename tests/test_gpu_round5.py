@@ -134,3 +134,101 @@ def test_cfg5_full_library_records_equal_form8_and_the_host_fold(gpu, hvd):
         assert np.array_equal(recs_auto, want), "video records differ from the host fold of the popcount kernel's frame pairs"
     finally:
         library.free()
+
+
+# ------------------------------------------------------------------ streaming feed: runs of frames (ABI 5) --------
+
+@pytest.mark.parametrize("geom", [(64, 64, 1, 700), (64, 64, 3, 300), (512, 512, 3, 40)])
+def test_videohasher_acquire_frames_runs(gpu, hvd, oracle, geom):
+    """acquire_frames(k) / commit_frames(n): a run of frames per FFI round trip, through a tiny batch so that runs are cut at
+    slot boundaries and the ring wraps; partial commits; mixed with hash_frame and the per-frame acquire. Results in feed
+    order, equal to the oracle's (vpdqpy/vpdqpy.py:113-119 contract: finish() = kept hashes in frame order)."""
+    w, h, ch, n = geom
+    fr = hvd.synth.frames_rgb(n, seed=81, h=h, w=w) if ch == 3 else hvd.synth.frames_gray(n, 82, h, w)
+    ho, qo = oracle.hash_frames(fr, num_threads=8)
+    want = ho[qo >= 31].tobytes()
+    for batch_bytes in (fr[0].nbytes * 37, 64 << 20):
+        hs = hvd.VideoHasher(1, w, h, 0, batch_bytes=batch_bytes)
+        k, step = 0, 0
+        while k < n:
+            step += 1
+            if step % 5 == 0:  # the unchanged reference call in between
+                hs.hash_frame(fr[k].tobytes())
+                k += 1
+            elif step % 5 == 1:  # the per-frame zero-copy feed
+                np.copyto(hs.acquire_frame(ch), fr[k])
+                hs.commit_frame()
+                k += 1
+            else:
+                run = hs.acquire_frames(min(n - k, 3 + 17 * (step % 7)), ch)
+                assert 1 <= run.shape[0] and run.shape[1:] == fr.shape[1:]
+                m = run.shape[0] if step % 3 else max(1, run.shape[0] // 2)  # sometimes only part of the run is used
+                np.copyto(run[:m], fr[k:k + m])
+                hs.commit_frames(m)
+                k += m
+        assert hs.finish().bytes == want
+    hs = hvd.VideoHasher(1, w, h, 0)
+    with pytest.raises(RuntimeError):
+        hs.commit_frames()
+    with pytest.raises(RuntimeError):
+        hs.commit_frame()
+    run = hs.acquire_frames(5, ch)
+    hs.commit_frames(0)  # a run may be given back unused
+    assert hs.finish().bytes == b""
+
+
+def test_hasher_acquire_n_c_abi(gpu, hvd, oracle):
+    """The same through the C-ABI directly: argument checks, run lengths capped by the batch slot, commit bounds."""
+    lib = gpu.load()
+    fr = hvd.synth.frames_gray(50, seed=83)
+    ho, qo = oracle.hash_frames(fr)
+    hdl = C.c_void_p()
+    gpu.check(lib.hvd_hasher_create(64, 64, 1, 16, C.byref(hdl)))
+    try:
+        p, got = C.c_void_p(), C.c_int64(0)
+        assert lib.hvd_hasher_acquire_n(hdl, 0, C.byref(p), C.byref(got)) == gpu.HVD_ERR_ARG
+        assert lib.hvd_hasher_commit_n(hdl, 1) == gpu.HVD_ERR_STATE
+        k = 0
+        while k < 50:
+            gpu.check(lib.hvd_hasher_acquire_n(hdl, 50 - k, C.byref(p), C.byref(got)))
+            assert 1 <= got.value <= 16 - (k % 16)
+            assert lib.hvd_hasher_commit_n(hdl, got.value + 1) == gpu.HVD_ERR_ARG  # more than acquired
+            gpu.check(lib.hvd_hasher_acquire_n(hdl, 50 - k, C.byref(p), C.byref(got)))
+            C.memmove(p.value, fr[k:].ctypes.data, 4096 * got.value)
+            gpu.check(lib.hvd_hasher_commit_n(hdl, got.value))
+            k += got.value
+        hh, qq, n_out = np.zeros((50, 32), np.uint8), np.zeros(50, np.int32), C.c_int64(0)
+        gpu.check(lib.hvd_hasher_finish(hdl, hh.ctypes.data, qq.ctypes.data, 50, C.byref(n_out)))
+        assert n_out.value == 50 and np.array_equal(hh, ho) and np.array_equal(qq, qo)
+    finally:
+        lib.hvd_hasher_destroy(hdl)
+
+
+def test_copy_nt_switch_is_bit_identical(gpu, hvd):
+    """hash_frame(bytes) through the non-temporal copy slices and through plain memcpy: same hashes (512x512 RGB24, the
+    reference's geometry; 1, 4 and 8 copy threads)."""
+    lib = gpu.load()
+    fr = hvd.synth.frames_rgb(24, seed=84)
+    h0, q0 = hvd.vpdq.hash_frames(fr)
+    want = h0[q0 >= 31].tobytes()
+    level = C.c_int(0)
+    gpu.check(lib.hvd_debug_get(b"copy_nt", C.byref(level)))
+    assert level.value in (0, 2, 3)
+    try:
+        for mode in (0, 1):
+            gpu.check(lib.hvd_debug_set(b"copy_nt", mode))
+            for threads in (1, 4, 8):
+                hs = hvd.VideoHasher(1, 512, 512, threads)
+                for f in fr:
+                    hs.hash_frame(f.tobytes())
+                assert hs.finish().bytes == want, (mode, threads)
+    finally:
+        gpu.check(lib.hvd_debug_set(b"copy_nt", 1))
+
+
+def test_runtime_info_names_the_device_and_the_libraries(gpu):
+    info = gpu.runtime_info()
+    assert info["abi"] == 5 and info["visible_devices"] >= 1
+    assert "gfx950" in info["devices"][0]["arch"] and info["devices"][0]["cus"] == 256
+    assert info["librccl_path"].endswith(".so") or ".so." in info["librccl_path"]
+    assert info["rccl_version"] > 20000 and info["hip_runtime_version"] > 0

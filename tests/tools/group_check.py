@@ -165,5 +165,35 @@ assert np.array_equal(recs_g, recs_1) and np.array_equal(pairs_g, pairs_1) and l
 planted = {(int(min(s, d)), int(max(s, d))) for d, s in enumerate(copy_of) if s >= 0}
 assert planted <= {tuple(p) for p in pairs_g.tolist()}
 
+# ---- a rank that dies BEFORE an exchange step must not strand the others: host-memory groups only -- aborting
+#      an RCCL group drops its communicators, which would end this script's group for good -------------------------------
+if L.group_exchange() == "host":
+    import threading
+
+    def dies_early(rank, world):
+        if rank == world - 1:
+            raise ValueError("rank failed before the exchange")
+        d = L.DeviceBuffer(16)
+        d.zero()
+        return M.GroupExchange(rank, world).allgather_pairs_dev(d.ptr, 1)
+
+    box = {}
+    th = threading.Thread(target=lambda: box.setdefault("exc", _raises(lambda: M.run_on_contexts(dies_early))), daemon=True)
+
+    def _raises(fn):
+        try:
+            fn()
+        except BaseException as exc:  # noqa: BLE001
+            return exc
+        return None
+
+    th.start()
+    th.join(60)
+    assert not th.is_alive(), "the surviving ranks are still waiting for the rank that failed"
+    assert isinstance(box["exc"], ValueError), repr(box["exc"])
+    # the next library-driven group call re-arms the barrier: the group works again
+    L.set_context(0)
+    assert np.array_equal(hvd_amd.allpairs_hamming(db, 31), want)
+
 L.shutdown()
 print("GROUP_OK", devs, "exchange", "host" if len(set(devs)) < W else "rccl")
