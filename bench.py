@@ -404,6 +404,17 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         rdzv.barrier()
 
     variant = search.DEFAULT_VARIANT if args.variant < 0 else args.variant
+    # what the ranks run on: versions, library paths, every rank's device, the peer links between them (xGMI or PCIe)
+    runtime = L.runtime_info()
+    my_dev = local_rank if inproc is not None else int(os.environ.get("HVD_FORCE_DEVICE", local_rank if local_rank < ndev else local_rank % ndev))
+    runtime["ranks"] = [json.loads(p_) for p_ in rdzv.allgather(json.dumps(
+        {"rank": rank, "device": my_dev, "pid": os.getpid(),
+         "pci": next((d_["pci"] for d_ in runtime["devices"] if d_["index"] == my_dev), "?"),
+         "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))}).encode())]
+    links = sorted({p_["link"] for p_ in runtime.get("peers", [])})
+    runtime["xgmi_or_pcie"] = "/".join(links) if links else ("single device" if runtime["visible_devices"] <= 1 else "?")
+    runtime["exchange"] = exchange_kind
+    runtime["group_exchange"] = L.group_exchange() if inproc is not None else "n/a (one process per GPU)"
 
     # ---------------- headline workload: replicated synthetic hash DB ---------------------------
     if args.mode == "cfg4":
@@ -427,26 +438,55 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         d_pairs = L.DeviceBuffer(16 * cap)
         d_cnt = L.DeviceBuffer(8)
         kms, my_pairs = [], [0]
+        # per timed step, on this rank (the first multi-GPU run must be readable from its one JSON line):
+        #   expand_ms   FP4 image of the DB (HIP events on the library stream)
+        #   kernel_ms   probe + form selection + all-pairs kernel over this rank's tiles (HIP events)
+        #   readback_ms pair count + this rank's records device -> host (host clock, after the kernel has finished)
+        #   exchange_ms the candidate exchange (RCCL all-gather of counts and padded records incl. their read-back; TCP in the
+        #               fallback; 0 at N = 1)
+        #   host_ms     the rest of the step's wall time: Python, ctypes, launch latency, the memset of the counter
+        split = {k: [] for k in ("expand_ms", "kernel_ms", "readback_ms", "exchange_ms", "host_ms", "step_ms")}
+
+        def between(a, b):
+            ms = C.c_float(0)
+            L.check(lib.hvd_timer_between(a, b, C.byref(ms)))
+            return float(ms.value)
 
         def step(timed=True):
+            t_a = time.perf_counter()
             d_cnt.zero()
+            L.check(lib.hvd_timer_mark(0))
             if v >= 8:  # the FP4 image is rebuilt inside every step: it is part of the pass, not a cached index
                 L.check(lib.hvd_dev_expand_fp4(d_db.ptr, n_, d_img.ptr))
-            L.check(lib.hvd_timer_start())
+            L.check(lib.hvd_timer_mark(1))
             M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n_, None, 31, rank, world, d_pairs.ptr, cap, d_cnt.ptr, v)
-            ms = C.c_float(0)
-            L.check(lib.hvd_timer_stop(C.byref(ms)))  # hipEvents on the library stream; also syncs
-            if timed:
-                kms.append(ms.value)
+            L.check(lib.hvd_timer_mark(2))
+            L.check(lib.hvd_dev_sync())  # the pass has finished on the device
+            t_k = time.perf_counter()
             cnt = int(d_cnt.to_array(np.uint64, 1)[0])
             if cnt > cap:
                 raise RuntimeError("pair buffer overflow in bench")
             my_pairs[0] = cnt
             if world == 1:
-                return d_pairs.to_array(L.PAIR_DTYPE, cnt)
-            if exchange is not None:
-                return exchange.allgather_pairs_dev(d_pairs.ptr, cnt)
-            return host_ex.allgather_pairs(d_pairs.to_array(L.PAIR_DTYPE, cnt))
+                out_ = d_pairs.to_array(L.PAIR_DTYPE, cnt)
+                t_r = t_x = time.perf_counter()
+            elif exchange is not None:
+                t_r = time.perf_counter()
+                out_ = exchange.allgather_pairs_dev(d_pairs.ptr, cnt)
+                t_x = time.perf_counter()
+            else:
+                mine_ = d_pairs.to_array(L.PAIR_DTYPE, cnt)
+                t_r = time.perf_counter()
+                out_ = host_ex.allgather_pairs(mine_)
+                t_x = time.perf_counter()
+            if timed:
+                e_ms, k_ms = between(0, 1), between(1, 2)
+                kms.append(k_ms)
+                r_ms, x_ms, s_ms = (t_r - t_k) * 1e3, (t_x - t_r) * 1e3, (t_x - t_a) * 1e3
+                for key, val in (("expand_ms", e_ms), ("kernel_ms", k_ms), ("readback_ms", r_ms), ("exchange_ms", x_ms),
+                                 ("host_ms", s_ms - e_ms - k_ms - r_ms - x_ms), ("step_ms", s_ms)):
+                    split[key].append(round(val, 3))
+            return out_
 
         for _ in range(warmup):
             step(timed=False)
@@ -469,8 +509,10 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         # every rank must hold the identical merged pair list after the exchange
         digest = int(np.bitwise_xor.reduce(merged.view(np.uint32).astype(np.uint64) *
                                            np.arange(1, merged.size * 4 + 1, dtype=np.uint64))) if merged.size else 0
-        per_rank = rdzv.allgather(json.dumps({"kernel_ms": round(float(np.mean(kms)), 3), "pairs": my_pairs[0],
-                                              "merged_pairs": int(merged.size), "digest": digest}).encode())
+        per_rank = rdzv.allgather(json.dumps({"rank": rank, "kernel_ms": round(float(np.mean(kms)), 3),
+                                              **{k_: round(float(np.mean(v_)), 3) for k_, v_ in split.items() if k_ != "kernel_ms"},
+                                              "pairs": my_pairs[0], "merged_pairs": int(merged.size), "digest": digest,
+                                              "steps": split}).encode())
         assert len({(json.loads(p)["merged_pairs"], json.loads(p)["digest"]) for p in per_rank}) == 1, \
             "ranks disagree on the merged pair list"
         res = {"elapsed": elapsed, "kernel_ms": kms, "merged": merged, "per_rank": [json.loads(p) for p in per_rank],
@@ -524,6 +566,21 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
     k_mean, k_sd = mean_sd(head["kernel_ms"])
     ms_per_step = elapsed / args.steps * 1e3
     value = total_cmp / (elapsed / args.steps)
+
+    # N > 1 in the default (weak) mode: BASELINE configs[2] itself -- fixed total work -- in the same run, so that one driver
+    # run per N yields both scaling curves
+    strong = None
+    if world > 1 and args.mode == "weak" and not args.no_extras:
+        k_s = max(1, min(args.steps, 10))
+        rs = allpairs_workload(args.hashes, 3, steps=k_s, warmup=1)
+        for b in rs["bufs"]:
+            b.free()
+        tc_s = args.hashes * (args.hashes - 1) // 2
+        strong = {"workload": f"BASELINE configs[2]: {args.hashes} hashes at every N (fixed total work), {k_s} timed steps",
+                  "value": sig(tc_s / (rs["elapsed"] / k_s), 5), "unit": "comparisons/s", "scaling": "strong", "n_gpus": world,
+                  "ms_per_step": round(rs["elapsed"] / k_s * 1e3, 3), "steps": k_s, "warmup": 1,
+                  "pairs_found": int(len(rs["merged"])), "per_rank": rs["per_rank"]}
+        del rs
 
     fr, d_h, d_q, k1_list, k1_wall = time_k1(args.frames, 50)
     k1_ms, k1_sd = mean_sd(k1_list)
@@ -584,7 +641,9 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                                                                        world, exchange, keep_library=True, timings=tm5)
                 barrier()
                 times.append(rdzv.allreduce_max([time.perf_counter() - t0])[0])
-                stage5.append(rdzv.allreduce_max([tm5["hash_ms"], tm5["search_ms"]]))
+                STAGES5 = ("hash_ms", "gather_ms", "compact_ms", "search_ms", "search_local_ms", "search_exchange_ms", "search_fold_ms")
+                stage5.append(rdzv.allreduce_max([tm5[k_] for k_ in STAGES5]))
+                mine5 = {k_: round(tm5[k_], 3) for k_ in STAGES5}
                 kept5, lens5 = lib5.n_frames, lib5.lengths()
                 lib5.free()
             fv5 = C.c_int(0)
@@ -600,7 +659,9 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             t5, t5_sd = mean_sd(times)
             fcmp5 = float((lens5.sum() ** 2 - (lens5 ** 2).sum()) / 2)  # frame comparisons between different videos
             hash5_ms, _ = mean_sd([x[0] for x in stage5])
-            search5_ms, search5_sd = mean_sd([x[1] for x in stage5])
+            search5_ms, search5_sd = mean_sd([x[3] for x in stage5])
+            stages5 = {k_: round(mean_sd([x[i_] for x in stage5])[0], 3) for i_, k_ in enumerate(STAGES5)}
+            per_rank5 = [json.loads(p_) for p_ in rdzv.allgather(json.dumps({"rank": rank, "last_pass": mine5}).encode())]
             # the search's kernel walks every tile of the upper triangle of kept x kept frames (pairs inside one video are
             # computed and then dropped): 2 MFMAs of 2*32*32*64 flop per 1024 comparisons in the first stage; the forms that
             # settle survivors on the matrix pipe execute more (PMC: profiles/r04_pmc_k2_*), the pair-queue form does not
@@ -628,6 +689,13 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                     "frames": V * F, "frames_kept": int(kept5), "videos_per_s": sig(V / t5), "frames_per_s_end_to_end": sig(V * F / t5),
                     "frame_comparisons": fcmp5, "frame_comparisons_per_s_end_to_end": sig(fcmp5 / t5),
                     "hash_ms": round(hash5_ms, 3), "search": search5,
+                    "stages_ms": {**stages5,
+                                  "what": "max over ranks, mean of 3 passes. hash / search: HIP events on the library stream; gather "
+                                          "(all-gather of the hash shards + squeeze), compact (quality filter + CSR), search_local "
+                                          "(packed hashes, probe, all-pairs pass, key set), search_exchange (agreement words, key-list "
+                                          "all-gather, merged set), search_fold (keys -> pair map): host clock around synchronous steps; "
+                                          "the rest of `seconds` is allocation, record read-back and Python"},
+                    "per_rank": per_rank5,
                     "video_records": int(len(recs5)), "duplicate_pairs": int(len(pairs5)),
                     "planted_copies": len(planted5), "planted_recall": round(len(planted5 & found5) / max(1, len(planted5)), 4),
                     "gate": "identical record checksum on every rank; tests/test_gpu_round2.py checks the same pipeline against "
@@ -741,6 +809,8 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             "cfg4": "`value`: all-pairs comparisons/s over BASELINE configs[3] (10M hashes, fixed total work) at every N",
         }[args.mode],
     }
+    if strong:
+        out["strong"] = strong
     if cfg4:
         out["config4"] = cfg4
     if cfg5:
@@ -1048,6 +1118,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         conn.close()
 
     out["frames_hashed"] = frames_out
+    out["runtime"] = runtime
     if cpu:
         out["cpu_baseline"] = cpu
         out["full_size_oracle_check"] = cpu["full_size_oracle_check"]

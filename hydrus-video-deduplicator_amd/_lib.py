@@ -93,6 +93,8 @@ SIGNATURES = {
     "hvd_allpairs_tile_geometry": (_int, [_i64, _int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "hvd_timer_start": (_int, []),
     "hvd_timer_stop": (_int, [C.POINTER(C.c_float)]),
+    "hvd_timer_mark": (_int, [_int]),
+    "hvd_timer_between": (_int, [_int, _int, C.POINTER(C.c_float)]),
     "hvd_comm_unique_id": (_int, [_vp]),
     "hvd_comm_init": (_int, [_vp, _int, _int]),
     "hvd_comm_allgather_pairs": (_int, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),

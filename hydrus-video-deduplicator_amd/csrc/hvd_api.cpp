@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -59,6 +60,9 @@ struct Ctx {
     bool host_exchange = false;  // group without RCCL (a device listed twice): exchange steps go through host memory
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t mark[8] = {};  // hvd_timer_mark / hvd_timer_between: created on first use
+    int v_us[3] = {0, 0, 0};  // last video search on this context, microseconds of host time: local phase (pack, probe, all-pairs
+                              // pass, key set), key exchange (agreement, all-gather, merged set), fold (pair map)
     float* d_dct = nullptr;
     float h_dct[16 * 64];
     bool comm_ready = false;
@@ -127,7 +131,7 @@ struct HostExchange {
         } else {
             cv.wait(lk, [&] { return gen != my || broken; });
         }
-        return !broken;
+        return gen != my;  // (completed: true even if a rank that left through it has broken it since)
     }
     void abort() {
         std::lock_guard<std::mutex> lk(mu);
@@ -301,6 +305,8 @@ void shutdown_context(int idx) {
         (void)hipFree(g.d_dct);
         (void)hipEventDestroy(g.ev0);
         (void)hipEventDestroy(g.ev1);
+        for (hipEvent_t m : g.mark)
+            if (m) (void)hipEventDestroy(m);
         (void)hipStreamDestroy(g.stream);
         for (void** p : {&g.m_a, &g.m_b, &g.m_f, &g.m_o})
             if (*p) (void)hipFree(*p);
@@ -633,6 +639,23 @@ int hvd_timer_stop(float* out_ms) {
     return HVD_OK;
 }
 
+int hvd_timer_mark(int slot) {
+    if (int rc = need_ready()) return rc;
+    if (slot < 0 || slot >= 8) return fail(HVD_ERR_ARG, "timer slot %d: 0..7", slot);
+    if (!g.mark[slot]) HIP_TRY(hipEventCreate(&g.mark[slot]));
+    HIP_TRY(hipEventRecord(g.mark[slot], g.stream));
+    return HVD_OK;
+}
+
+int hvd_timer_between(int slot_a, int slot_b, float* out_ms) {
+    if (int rc = need_ready()) return rc;
+    if (!out_ms || slot_a < 0 || slot_a >= 8 || slot_b < 0 || slot_b >= 8) return fail(HVD_ERR_ARG, "timer slots 0..7, out_ms not NULL");
+    if (!g.mark[slot_a] || !g.mark[slot_b]) return fail(HVD_ERR_STATE, "hvd_timer_between: a slot was never marked");
+    HIP_TRY(hipEventSynchronize(g.mark[slot_b]));
+    HIP_TRY(hipEventElapsedTime(out_ms, g.mark[slot_a], g.mark[slot_b]));
+    return HVD_OK;
+}
+
 int hvd_set_pdq_dct_mode(int mode) {
     if (mode != HVD_DCT_STRICT && mode != HVD_DCT_FMA) return fail(HVD_ERR_ARG, "unknown DCT mode %d", mode);
     hvd::g_pdq_dct_mode = mode;
@@ -754,6 +777,14 @@ int hvd_debug_get(const char* key, int* out_value) {
             *out_value = (int)v[k];
             return HVD_OK;
         }
+    {
+        const char* vk[3] = {"vmatch_us_local", "vmatch_us_exchange", "vmatch_us_fold"};
+        for (int k = 0; k < 3; ++k)
+            if (strcmp(key, vk[k]) == 0) {
+                *out_value = g.v_us[k];
+                return HVD_OK;
+            }
+    }
     if (strncmp(key, "mfma_qstat", 10) == 0 && key[10] >= '0' && key[10] <= '9') {  // HVD_K2_QSTATS builds (dev tool); reading clears
         const int k = atoi(key + 10);
         if (k < 0 || k > 15) return fail(HVD_ERR_ARG, "mfma_qstat0..15");
@@ -1382,8 +1413,15 @@ int vmatch_build(const VmArgs& v) {
     }
     return HVD_OK;
     };
-    const int local_rc = local();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto us_since = [](std::chrono::steady_clock::time_point t0) {
+        return (int)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    };
+    const int local_rc = local();  // (ends in read_counters: the stream is drained, host time is device time)
+    g.v_us[0] = us_since(t_begin);
+    g.v_us[1] = g.v_us[2] = 0;
     if (!exchange && local_rc) return local_rc;
+    const auto t_exchange = std::chrono::steady_clock::now();
     const unsigned long long* d_src = d_set;
     unsigned long long n_src = slots, n_keys = c[1];
     if (exchange) {
@@ -1467,7 +1505,9 @@ int vmatch_build(const VmArgs& v) {
         d_src = d_set2;
         n_src = slots2;
         n_keys = c[1];
+        g.v_us[1] = us_since(t_exchange);
     }
+    const auto t_fold = std::chrono::steady_clock::now();
     unsigned long long pslots = pow2_at_least(std::max<unsigned long long>(1024, 4ull * n_keys));
     if (g.v_force_slots_log2) pslots = 1ull << g.v_force_slots_log2;
     for (;;) {
@@ -1485,6 +1525,7 @@ int vmatch_build(const VmArgs& v) {
         pslots *= 4;
     }
     g.v_pslots = pslots;
+    g.v_us[2] = us_since(t_fold);
     return HVD_OK;
 }
 

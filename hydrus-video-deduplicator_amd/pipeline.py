@@ -223,7 +223,12 @@ def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, 
     -> pair predicate of dedup.py:445-502 on the few video-level records.
     -> (pairs int64[m,2], records, library or None). Every rank returns the same result.
     timings (optional dict): receives hash_ms and search_ms, HIP-event times on the library stream of the hash launch
-    and of the whole video search (image, probe, all-pairs pass, key reduction, record emit)."""
+    and of the whole video search (image, probe, all-pairs pass, key reduction, record emit); gather_ms (host clock: the
+    all-gather of the hash shards over RCCL incl. the squeeze into library order, 0 at world 1), compact_ms (host clock:
+    quality filter + CSR, synchronous) and the search's own phases from the library (host clock, hvd_debug_get
+    vmatch_us_*): search_local_ms (packed hashes, probe, all-pairs pass, key set), search_exchange_ms (agreement words,
+    all-gather of the key lists, merged set; 0 at world 1), search_fold_ms (keys -> pair map)."""
+    import time
     raw_offsets = np.ascontiguousarray(raw_offsets, dtype=np.int64)
     V = raw_offsets.size - 1
     n_total = int(raw_offsets[-1])
@@ -242,6 +247,7 @@ def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, 
         return out
 
     d_h, d_q = timed("hash_ms", lambda: hash_frames_on_device(d_frames_ptr, n_mine, h, w, channels))
+    t0 = time.perf_counter()
     if world > 1:
         if exchange is None:
             raise ValueError("world > 1 needs the RCCL exchange")
@@ -249,10 +255,19 @@ def dedupe_frames_on_device(d_frames_ptr: int, raw_offsets: np.ndarray, h: int, 
         d_h.free()
         d_q.free()
         d_h, d_q = d_fh, d_fq
+    t1 = time.perf_counter()
     library = DeviceLibrary.from_raw_hashes(d_h.ptr, d_q.ptr, n_total, raw_offsets)
+    t2 = time.perf_counter()
     d_h.free()
     d_q.free()
     recs = timed("search_ms", lambda: library.match_videos(rank=rank, world=world))
+    if timings is not None:
+        timings["gather_ms"] = (t1 - t0) * 1e3 if world > 1 else 0.0
+        timings["compact_ms"] = (t2 - t1) * 1e3
+        us = C.c_int(0)
+        for key in ("local", "exchange", "fold"):
+            _lib.check(lib.hvd_debug_get(f"vmatch_us_{key}".encode(), C.byref(us)))
+            timings[f"search_{key}_ms"] = us.value / 1e3
     pairs = search.similar_video_pairs(recs, library.lengths(), threshold, policy)
     if keep_library:
         return pairs, recs, library

@@ -39,7 +39,7 @@ extern "C" {
 
 #define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
 #define HVD_UNIQUE_ID_BYTES 128
-#define HVD_ABI_VERSION 5 /* 5 (round 5): + hvd_hasher_acquire_n, hvd_hasher_commit_n, hvd_group_abort, hvd_runtime_info; 4 (round 4): + hvd_init_devices, hvd_context_count, hvd_set_context, hvd_get_context, hvd_group_exchange; 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
+#define HVD_ABI_VERSION 5 /* 5 (round 5): + hvd_hasher_acquire_n, hvd_hasher_commit_n, hvd_group_abort, hvd_runtime_info, hvd_timer_mark, hvd_timer_between; 4 (round 4): + hvd_init_devices, hvd_context_count, hvd_set_context, hvd_get_context, hvd_group_exchange; 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
 /* All-pairs kernel the host entry points use: FP4-MFMA with a 128-bit first stage; which of its two forms runs
  * (survivors fetch their other half | second stage out of registers) is chosen per launch from a probe of the data. */
 #define HVD_DEFAULT_VARIANT 13
@@ -221,7 +221,11 @@ int hvd_get_pdq_dct_mode(void);
 int hvd_debug_set(const char* key, int value);
 /* "mfma_auto_form": the form (9, 18 or 12; 15..19 if "mfma_auto_mid" says so) the last auto-variant launch ran;
  * "mfma_probe_survivors" / "mfma_probe_survivors_hi": what its probe counted over bits 0..127 / 128..255; "mfma_auto_half":
- * 1 if the first stage ran on bits 128..255. Synchronises the library stream. */
+ * 1 if the first stage ran on bits 128..255. Synchronises the library stream.
+ * "vmatch_us_local" / "vmatch_us_exchange" / "vmatch_us_fold": host microseconds of the three phases of the last video-level
+ * search on the calling thread's context (local: packed hashes, probe, all-pairs pass, key set; exchange: agreement words,
+ * all-gather of the key lists, merged set -- 0 at world 1; fold: keys -> pair map). "copy_nt": 0 | 2 | 3 = plain memcpy |
+ * AVX2 | AVX-512 streaming stores in hvd_hasher_push (hvd_debug_set "copy_nt" 0|1; HVD_COPY_NT=0 in the environment). */
 int hvd_debug_get(const char* key, int* out_value);
 
 /* Bytes of device scratch hvd_dev_pdq_hash_frames needs for this geometry (0 for
@@ -299,6 +303,11 @@ int hvd_allpairs_tile_geometry(int64_t n, int variant, uint32_t* rows_per_block,
 /* hipEvent pair on the library stream: wall time of everything enqueued between. */
 int hvd_timer_start(void);
 int hvd_timer_stop(float* out_ms);
+/* Eight event slots per context for split timings without extra synchronisation (ABI 5): hvd_timer_mark(k) records event k
+ * on the library stream and returns at once; hvd_timer_between(a, b, &ms) waits for event b and returns the device time
+ * between the two. bench.py marks expand | kernel | end of a step and reads both intervals after the step's own sync. */
+int hvd_timer_mark(int slot);
+int hvd_timer_between(int slot_a, int slot_b, float* out_ms);
 
 /* ----------------------------------------------- multi-GPU exchange ------ */
 /* One process per GPU; rank 0 creates the id, the caller's control channel hands it to the other ranks

@@ -116,6 +116,7 @@ def test_bench_self_launches_two_ranks_on_one_gpu(gpu):
     assert all(p["kernel_ms"] > 0 for p in out["per_rank"])
     assert sum(p["pairs"] for p in out["per_rank"]) == out["config"]["pairs_found"]
     assert "scale_metric" in out and out["scaling"] == "weak"
+    _check_breakdown(out, steps=2, world=2)
     assert b"import torch" not in open(os.path.join(ROOT, "bench.py"), "rb").read()
 
 
@@ -143,3 +144,33 @@ def test_single_process_bench_runs_two_contexts_on_one_gpu():
     assert out["config"]["exchange"].startswith("host-memory")
     assert len(out["per_rank"]) == 2 and all(p["pairs"] > 0 for p in out["per_rank"])
     assert out["config5"]["planted_recall"] == 1.0 and out["config4"]["pairs_found"] > 0
+    _check_breakdown(out, steps=2, world=2)
+    assert out["runtime"]["group_exchange"] == "host"
+    # both scaling curves from one run: the weak headline and BASELINE configs[2] itself (fixed total work)
+    assert out["strong"]["scaling"] == "strong" and out["strong"]["n_gpus"] == 2 and out["strong"]["value"] > 0
+    assert len(out["strong"]["per_rank"]) == 2 and out["strong"]["per_rank"][0]["steps"]["kernel_ms"]
+    # config 4 / config 5 carry the same split
+    assert len(out["config4"]["per_rank"]) == 2 and "exchange_ms" in out["config4"]["per_rank"][1]
+    st = out["config5"]["stages_ms"]
+    for key in ("hash_ms", "gather_ms", "compact_ms", "search_ms", "search_local_ms", "search_exchange_ms", "search_fold_ms"):
+        assert st[key] >= 0, key
+    assert st["search_local_ms"] > 0 and st["search_exchange_ms"] > 0 and st["gather_ms"] > 0
+    assert [p["rank"] for p in out["config5"]["per_rank"]] == [0, 1]
+
+
+def _check_breakdown(out, steps, world):
+    """every rank's per-step split and what the ranks run on are in the one JSON line."""
+    keys = ("expand_ms", "kernel_ms", "readback_ms", "exchange_ms", "host_ms", "step_ms")
+    assert [p["rank"] for p in out["per_rank"]] == list(range(world))
+    for p in out["per_rank"]:
+        for k in keys:
+            assert len(p["steps"][k]) == steps and isinstance(p[k], float), (k, p)
+        assert all(x > 0 for x in p["steps"]["kernel_ms"]) and all(x > 0 for x in p["steps"]["exchange_ms"])
+        for i in range(steps):  # the parts add up to the step
+            parts = sum(p["steps"][k][i] for k in keys[:-1])
+            assert abs(parts - p["steps"]["step_ms"][i]) < 0.02, (parts, p["steps"]["step_ms"][i])
+    rt = out["runtime"]
+    assert rt["rccl_version"] > 20000 and rt["hip_runtime_version"] > 0 and "librccl" in rt["librccl_path"]
+    assert rt["devices"] and "gfx950" in rt["devices"][0]["arch"]
+    assert [r["rank"] for r in rt["ranks"]] == list(range(world)) and all("device" in r and "pci" in r for r in rt["ranks"])
+    assert rt["xgmi_or_pcie"] and rt["exchange"] == out["config"]["exchange"]
