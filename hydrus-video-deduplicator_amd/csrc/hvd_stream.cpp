@@ -72,6 +72,7 @@ struct hvd_hasher {
     std::vector<uint8_t> hashes;   // collected results, frame order
     std::vector<int32_t> quality;
     bool acquired = false;         // hvd_hasher_acquire handed out the next frame's slot memory
+    int64_t acquired_n = 0;        // ... and hvd_hasher_acquire_n this many frames of it
 };
 
 // A hasher lives on the context it was created on, whatever context the calling thread has selected.
@@ -245,6 +246,7 @@ int hvd_hasher_acquire(hvd_hasher* hs, uint8_t** out_frame) {
     }
     *out_frame = s.h_frames + hs->frame_bytes * (size_t)s.filled;
     hs->acquired = true;
+    hs->acquired_n = 1;
     return HVD_OK;
 }
 
@@ -271,7 +273,7 @@ int hvd_hasher_acquire_n(hvd_hasher* hs, int64_t want, uint8_t** out_frames, int
     if (want < 1) return hvd::api_fail(HVD_ERR_ARG, "want must be at least 1");
     if (int rc = hvd_hasher_acquire(hs, out_frames)) return rc;
     const Slot& s = hs->slot[hs->cur];
-    *out_n = std::min<int64_t>(want, hs->batch - s.filled);
+    *out_n = hs->acquired_n = std::min<int64_t>(want, hs->batch - s.filled);
     return HVD_OK;
 }
 
@@ -280,7 +282,7 @@ int hvd_hasher_commit_n(hvd_hasher* hs, int64_t n) {
     CtxScope scope(hs->ctx);
     if (!hs->acquired) return hvd::api_fail(HVD_ERR_STATE, "hvd_hasher_commit_n() without hvd_hasher_acquire_n()");
     Slot& s = hs->slot[hs->cur];
-    if (n < 0 || n > hs->batch - s.filled) return hvd::api_fail(HVD_ERR_ARG, "commit of %lld frames, %lld acquired at most", (long long)n, (long long)(hs->batch - s.filled));
+    if (n < 0 || n > hs->acquired_n) return hvd::api_fail(HVD_ERR_ARG, "commit of %lld frames, %lld acquired", (long long)n, (long long)hs->acquired_n);
     if (int rc = hvd::api_bind_device()) return rc;
     hs->acquired = false;
     s.filled += n;

@@ -80,13 +80,22 @@ class VpTreeManager:
     # the tree has degenerated; the leaf is then NOT inserted, `tree_incomplete` is set and a warning says what to do
     # before the reference's tree is used again (its --clear-search-tree / regenerate_tree rebuilds it from
     # shape_perceptual_hashes, where every hash still is).
+    # The condition is PERSISTED: the skipped phash ids go into a marker table of the database, so that every
+    # later manager on that file warns again -- and knows -- until the reference has rebuilt its tree (rows whose hash has
+    # reached shape_vptree since are dropped at the next look).
+    # Round 5: the upkeep of the reference's tree is OPT-IN. The tree is out of this build's scope
+    #  and the facade's own search never reads it; a database that goes back to the reference's
+    # tree runs the reference's --clear-search-tree once, which rebuilds it from shape_perceptual_hashes.
     MAX_TREE_WALK = 128
+    SKIPPED_TABLE = "hvd_vptree_skipped"
 
-    def __init__(self, db, matcher=None, maintain_reference_tree: bool = True):
+    def __init__(self, db, matcher=None, maintain_reference_tree: bool = False):
         self.db = db
         self._matcher = search if matcher is None else matcher  # tests inject a CPU stand-in
         self._maintain_tree = maintain_reference_tree
         self.tree_incomplete = False  # a leaf was left out of shape_vptree because the walk exceeded MAX_TREE_WALK
+        if maintain_reference_tree:
+            self._check_skipped_marker()
         self._index = {}          # phash_id -> position
         self._phash_ids = []      # position -> phash_id
         self._blobs = []          # position -> bytes
@@ -118,6 +127,23 @@ class VpTreeManager:
         if not self._loaded or perceptual_hash_id in self._index:
             return
         self._append(perceptual_hash_id, perceptual_hash)
+
+    def _check_skipped_marker(self) -> None:
+        """Leaves an earlier manager left out of shape_vptree on this database: still missing -> warn again."""
+        try:
+            self.db.execute(f"DELETE FROM {self.SKIPPED_TABLE} WHERE phash_id IN ( SELECT phash_id FROM shape_vptree );")
+            (n,) = self.db.execute(f"SELECT COUNT(*) FROM {self.SKIPPED_TABLE};").fetchone()
+        except Exception as exc:  # noqa: BLE001 - no marker table (nothing was ever skipped) / no tree tables
+            if "no such table" in str(exc):
+                return
+            raise
+        if n:
+            import warnings
+
+            self.tree_incomplete = True
+            warnings.warn(f"{n} perceptual hashes of this database are missing from shape_vptree (left out by an earlier "
+                          "run: the tree had degenerated); run the reference's --clear-search-tree before using its tree "
+                          "on this database", RuntimeWarning, stacklevel=3)
 
     def _distance(self, a: bytes, b: bytes) -> int:
         fn = getattr(self._matcher, "calculate_distance", None)
@@ -158,6 +184,8 @@ class VpTreeManager:
                         "--clear-search-tree (regenerate_tree) before using its tree on this database again",
                         RuntimeWarning, stacklevel=3)
                 self.tree_incomplete = True
+                self.db.execute(f"CREATE TABLE IF NOT EXISTS {self.SKIPPED_TABLE} ( phash_id INTEGER PRIMARY KEY );")
+                self.db.execute(f"INSERT OR IGNORE INTO {self.SKIPPED_TABLE} ( phash_id ) VALUES ( ? );", (phash_id,))
                 return
             row = self.db.execute(
                 "SELECT phash, radius, inner_id, inner_population, outer_id, outer_population FROM shape_perceptual_hashes "

@@ -232,3 +232,15 @@ def test_runtime_info_names_the_device_and_the_libraries(gpu):
     assert "gfx950" in info["devices"][0]["arch"] and info["devices"][0]["cus"] == 256
     assert info["librccl_path"].endswith(".so") or ".so." in info["librccl_path"]
     assert info["rccl_version"] > 20000 and info["hip_runtime_version"] > 0
+
+
+def test_gpu_test_process_runs_on_the_system_rocm_not_on_torchs_bundle(gpu):
+    """The product never imports torch, and neither may the process that tests it: with torch loaded first, its bundled
+    libamdhip64 / librccl (another ROCm release) would serve this library's calls. The libraries behind the symbols this
+    library calls must be the ones it was linked against (/opt/rocm), and the RCCL at run time the one it was built for."""
+    import sys
+
+    assert "torch" not in sys.modules, "a test module imported torch at collection time"
+    info = gpu.runtime_info()
+    assert "/torch/" not in info["librccl_path"] and "/torch/" not in info["libamdhip64_path"], info
+    assert info["rccl_version"] == info["rccl_built_against"], info

@@ -10,7 +10,6 @@ import sys
 
 import numpy as np
 import pytest
-import torch.multiprocessing as mp
 
 from conftest import ROOT, load_golden
 
@@ -122,6 +121,11 @@ def _worker(rank, world, port, q, kind):
 @pytest.mark.parametrize("kind,world", [("tcp", 2), ("tcp", 3), ("gloo", 2)])
 def test_sharded_allpairs_multi_process(oracle, kind, world):
     port = _free_port()
+    # torch is imported HERE, not at module level: pytest imports every test module at collection, and a `-m gpu` process
+    # that had torch loaded would hand torch's bundled libamdhip64 / librccl to libhvd_mi355x.so (the RCCL banner of the
+    # round-4 GPU run named torch's librccl for exactly that reason)
+    import torch.multiprocessing as mp
+
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]

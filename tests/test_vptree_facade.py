@@ -264,7 +264,7 @@ def test_add_leaf_keeps_the_reference_tree_valid(hvd, oracle):
     # the reference creates one manager per inserted file (db/DedupeDB.py:303-304): do the same
     class PerFile:
         def add_leaf(self, pid, blob):
-            hvd.vptree.VpTreeManager(conn, matcher=m).add_leaf(pid, blob)
+            hvd.vptree.VpTreeManager(conn, matcher=m, maintain_reference_tree=True).add_leaf(pid, blob)
 
     assert hvd.sqlite_adapter.ingest_phashed_file_queue(conn, tree=PerFile()) == len(blobs)
     _check_tree_is_valid(conn, m.calculate_distance)
@@ -341,7 +341,7 @@ def _alternation_checks(gen):
 
     random.seed(4)  # the reference's tree uses unseeded random sampling when it rebalances; none happens at this size
     ref_only = build(lambda k: gen.vptree.VpTreeManager)
-    mixed = build(lambda k: gen.vptree.VpTreeManager if k % 2 == 0 else (lambda db: ours.VpTreeManager(db, matcher=m)))
+    mixed = build(lambda k: gen.vptree.VpTreeManager if k % 2 == 0 else (lambda db: ours.VpTreeManager(db, matcher=m, maintain_reference_tree=True)))
     # same rule, same distances, same insertion order -> the very same tree
     q = "SELECT phash_id, parent_id, radius, inner_id, inner_population, outer_id, outer_population FROM shape_vptree ORDER BY phash_id"
     assert mixed.execute(q).fetchall() == ref_only.execute(q).fetchall()
@@ -469,7 +469,7 @@ def test_add_leaf_cost_is_bounded_on_a_degenerate_tree(hvd, oracle):
 
     class PerFile:  # the reference's pattern: one manager per inserted file (db/DedupeDB.py:303-304)
         def add_leaf(self, pid, blob):
-            t = hvd.vptree.VpTreeManager(conn, matcher=m)
+            t = hvd.vptree.VpTreeManager(conn, matcher=m, maintain_reference_tree=True)
             t.add_leaf(pid, blob)
             incomplete.append(t.tree_incomplete)
 
@@ -482,6 +482,25 @@ def test_add_leaf_cost_is_bounded_on_a_degenerate_tree(hvd, oracle):
     in_tree = conn.execute("SELECT COUNT(*) FROM shape_vptree").fetchone()[0]
     assert cap <= in_tree <= cap + 1 and incomplete.count(True) == n - in_tree
     _check_tree_is_valid(conn, m.calculate_distance, complete=False)  # what IS in the tree is still a valid tree
+    # the condition is persisted in the database: the marker table lists exactly the hashes that were left out,
+    # a later manager that maintains the tree warns again, one that does not (the default) stays silent
+    skipped = {r[0] for r in conn.execute("SELECT phash_id FROM hvd_vptree_skipped")}
+    in_tree_ids = {r[0] for r in conn.execute("SELECT phash_id FROM shape_vptree")}
+    all_ids = {r[0] for r in conn.execute("SELECT phash_id FROM shape_perceptual_hashes")}
+    assert skipped == all_ids - in_tree_ids and len(skipped) == n - in_tree
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        later = hvd.vptree.VpTreeManager(conn, matcher=m, maintain_reference_tree=True)
+        assert later.tree_incomplete and any("missing from shape_vptree" in str(x.message) for x in w2)
+        n_w = len(w2)
+        assert not hvd.vptree.VpTreeManager(conn, matcher=m).tree_incomplete and len(w2) == n_w
+    # once the reference has rebuilt its tree (here: the rows appear in shape_vptree) the marker empties itself
+    for pid in skipped:
+        conn.execute("INSERT INTO shape_vptree ( phash_id, parent_id, radius, inner_id, inner_population, outer_id, outer_population ) "
+                     "VALUES ( ?, -1, NULL, NULL, 0, NULL, 0 )", (pid,))
+    assert not hvd.vptree.VpTreeManager(conn, matcher=m, maintain_reference_tree=True).tree_incomplete
+    assert conn.execute("SELECT COUNT(*) FROM hvd_vptree_skipped").fetchone()[0] == 0
+    conn.execute("DELETE FROM shape_vptree WHERE parent_id = -1")
     # the facade's search sees every file regardless
     tree = hvd.vptree.VpTreeManager(conn, matcher=m)
     res = tree.search_file(4, 101)  # radius 101 = "similarity below 1 %": every file, the capped-out ones included
