@@ -131,8 +131,9 @@ def videohasher_stream_leg(lib, L, synth, vpdq):
       bytes         hash_frame(bytes)            what the unchanged reference loop passes (a 786 KB memcpy into the ring)
       buffer        hash_frame(ndarray row)      any buffer object, same memcpy, no bytes object
       acquire_copy  acquire_frame() + np.copyto + commit_frame()   a decoder writing at memcpy speed into the pinned slot
-      acquire_only  acquire_frame() + commit_frame()               the feed's own ceiling: slot contents left as the previous
-                                                                   video wrote them (same frames, same positions)
+      acquire_only  acquire_frame() + commit_frame()               the feed's own ceiling: nothing is written, the slots keep what
+                                                                   a warm-up video wrote (a video of ONE repeated frame, so that
+                                                                   every slot position holds it whatever the batch layout)
       acquire_run   acquire_frames(k) + ONE np.copyto per run + commit_frames()   a decoder that fills a run of frames per call
       bytes_memcpy  hash_frame(bytes) with the ring copy as plain memcpy (hvd_debug_set copy_nt 0): the A/B of the
                     non-temporal stores the copy slices use by default (round 5)
@@ -169,7 +170,11 @@ def videohasher_stream_leg(lib, L, synth, vpdq):
         res = {"frames_per_video": frames_per_video, "videos": n_videos, "frame_bytes": fb,
                "frames_kept_per_video": len(want) // 32}
 
-        def run(feed):
+        same = np.ascontiguousarray(np.broadcast_to(distinct[:1], video.shape))  # acquire_only: one frame, repeated
+        hs_, qs_ = vpdq.hash_frames(same[:1])
+        want_same = (hs_[:1].tobytes() * frames_per_video) if qs_[0] >= 31 else b""
+
+        def run(feed, video=video):
             hs = vpdq.VideoHasher(1, w, h, 0)
             if feed == "bytes":
                 for f in as_bytes:
@@ -203,11 +208,16 @@ def videohasher_stream_leg(lib, L, synth, vpdq):
                     continue
                 L.check(lib.hvd_debug_set(b"copy_nt", 0))
             real = "bytes" if feed == "bytes_memcpy" else feed
-            assert run("acquire_copy" if feed == "acquire_only" else real).bytes == want  # warm-up, fills the slots
+            if feed == "acquire_only":
+                assert run("acquire_copy", same).bytes == want_same  # warm-up: every slot position now holds that frame
+                expect = want_same
+            else:
+                assert run(real).bytes == want  # warm-up
+                expect = want
             t = time.perf_counter()
             for _ in range(n_videos):
                 got = run(real)
-                assert got.bytes == want, f"VideoHasher({feed}) differs from the batch entry point"
+                assert got.bytes == expect, f"VideoHasher({feed}) differs from the batch entry point"
             dt = time.perf_counter() - t
             if feed == "bytes_memcpy":
                 L.check(lib.hvd_debug_set(b"copy_nt", 1))

@@ -763,6 +763,14 @@ int hvd_debug_get(const char* key, int* out_value) {
         *out_value = hvd::stream_copy_nt_level();
         return HVD_OK;
     }
+    {
+        const char* hk[3] = {"hasher_us_copy", "hasher_us_submit", "hasher_us_wait"};
+        for (int k = 0; k < 3; ++k)
+            if (strcmp(key, hk[k]) == 0) {  // host microseconds of the streaming feed since the last read (process-wide; reading clears)
+                *out_value = (int)std::min<long long>(hvd::stream_take_ns(k) / 1000, 0x7FFFFFFF);
+                return HVD_OK;
+            }
+    }
     if (int rc = need_ready()) return rc;
     // what the probe of the last auto-variant launch saw and chose: form id, survivors over bits 0..127 / 128..255,
     // 1 if the first stage ran on bits 128..255

@@ -46,6 +46,7 @@ void pdq_release();           // k_pdq.hip: free the hash kernel's work-counter 
 void stream_release_cache();  // hvd_stream.cpp: free the parked hasher slot sets (hvd_shutdown)
 void stream_set_copy_nt(int on);  // hvd_stream.cpp / copy_pool.h: non-temporal stores into the pinned ring (debug key "copy_nt")
 int stream_copy_nt_level();
+long long stream_take_ns(int which);  // 0 copy, 1 submit, 2 wait: host time of the streaming feed since the last read
 bool allpairs_mfma_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 
 // Video-level reduction and quality compaction (k_vmatch.hip).

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -51,7 +52,20 @@ struct Slot {
 
 namespace {
 hvd::CopyPool g_copy_pool;  // (copy_pool.h)
+// where the host side of the feed spends its time, process-wide, in nanoseconds (hvd_debug_get "hasher_ns_copy" / "_submit" /
+// "_wait"; reading clears): the frame copies into the ring, the enqueue of a batch (H2D + kernels + D2H + event), the waits for
+// a slot whose previous batch is still in flight. Three clock reads per frame (~60 ns).
+std::atomic<long long> g_ns_copy{0}, g_ns_submit{0}, g_ns_wait{0};
+struct NsScope {
+    std::atomic<long long>& acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit NsScope(std::atomic<long long>& a) : acc(a) {}
+    ~NsScope() { acc.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
+};
 }  // namespace
+namespace hvd {
+long long stream_take_ns(int which) { return (which == 0 ? g_ns_copy : which == 1 ? g_ns_submit : g_ns_wait).exchange(0); }
+}
 
 #ifndef HVD_NO_BENCH_SYMBOLS
 extern "C" int hvd_debug_parallel_copy(void* dst, const void* src, size_t n, int threads) {
@@ -65,7 +79,8 @@ struct hvd_hasher {
     int ctx = 0;           // the context (device of the group) this hasher was created on: every call runs there
     int copy_threads = 4;  // threads that share one frame's copy into the ring (hvd_hasher_set_threads)
     int w = 0, h = 0, channels = 0;
-    int64_t batch = 0;
+    int64_t batch = 0;             // frames a slot holds
+    int64_t limit = 0;             // frames after which the CURRENT batch is submitted: ramps up to `batch` (first_limit)
     size_t frame_bytes = 0;
     Slot slot[kSlots];
     int cur = 0;
@@ -74,6 +89,16 @@ struct hvd_hasher {
     bool acquired = false;         // hvd_hasher_acquire handed out the next frame's slot memory
     int64_t acquired_n = 0;        // ... and hvd_hasher_acquire_n this many frames of it
 };
+
+// A video starts on an empty pipeline (the reference makes one hasher per video and finish() drains it, vpdqpy/vpdqpy.py:113-119):
+// with full 64 MiB batches the DMA engine idled for the whole first batch's fill time at the start of every video -- 0.94 ms of a
+// 5.5 ms video of 300 frames at 512x512 (profiles/r05_vh_where.txt). The first batch of a video is therefore SMALL (8 MiB of
+// frames) and the batch size doubles from submit to submit up to the slot's capacity; finish() starts the ramp again. Frames of
+// 4 KB never leave the first step (2048 of them), so the small-frame path still submits once per video.
+static int64_t first_limit(const hvd_hasher* hs) {
+    const int64_t f = (int64_t)(((size_t)8 << 20) / hs->frame_bytes);
+    return std::max<int64_t>(1, std::min<int64_t>(hs->batch, f));
+}
 
 // A hasher lives on the context it was created on, whatever context the calling thread has selected.
 namespace {
@@ -95,7 +120,10 @@ struct CtxScope {
 
 static int collect(hvd_hasher* hs, Slot& s) {
     if (s.in_flight == 0) return HVD_OK;
-    S_TRY(hipEventSynchronize(s.done));
+    {
+        NsScope ns(g_ns_wait);
+        S_TRY(hipEventSynchronize(s.done));
+    }
     hs->hashes.insert(hs->hashes.end(), s.h_hashes, s.h_hashes + 32 * s.in_flight);
     hs->quality.insert(hs->quality.end(), s.h_quality, s.h_quality + s.in_flight);
     s.in_flight = 0;
@@ -104,6 +132,7 @@ static int collect(hvd_hasher* hs, Slot& s) {
 
 static int submit(hvd_hasher* hs, Slot& s) {
     if (s.filled == 0) return HVD_OK;
+    NsScope ns(g_ns_submit);
     const int64_t m = s.filled;
     S_TRY(hipMemcpyAsync(s.d_frames, s.h_frames, hs->frame_bytes * (size_t)m, hipMemcpyHostToDevice, s.stream));
     S_TRY(hvd::api_launch_hash(s.d_frames, m, hs->h, hs->w, hs->channels, s.d_scratch, s.d_hashes, s.d_quality, s.stream));
@@ -112,6 +141,7 @@ static int submit(hvd_hasher* hs, Slot& s) {
     S_TRY(hipEventRecord(s.done, s.stream));
     s.in_flight = m;
     s.filled = 0;
+    hs->limit = std::min<int64_t>(hs->batch, 2 * hs->limit);
     return HVD_OK;
 }
 
@@ -171,6 +201,7 @@ int hvd_hasher_destroy(hvd_hasher* hs) {
         hs->quality.clear();
         hs->cur = 0;
         hs->acquired = false;
+        hs->limit = first_limit(hs);
         std::lock_guard<std::mutex> lk(g_park_mu);
         g_parked.push_back(hs);
         if (g_parked.size() > kMaxParked) {
@@ -210,6 +241,7 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
     hs->channels = channels;
     hs->batch = batch_frames;
     hs->frame_bytes = (size_t)width * height * channels;
+    hs->limit = first_limit(hs);
     const size_t scratch = hvd::api_scratch_bytes(batch_frames, height, width, channels);
     for (Slot& s : hs->slot) {
         hipError_t e = hipSuccess;
@@ -257,7 +289,7 @@ int hvd_hasher_commit(hvd_hasher* hs) {
     if (int rc = hvd::api_bind_device()) return rc;
     hs->acquired = false;
     Slot& s = hs->slot[hs->cur];
-    if (++s.filled == hs->batch) {
+    if (++s.filled >= hs->limit) {
         if (int rc = submit(hs, s)) return rc;
         hs->cur = (hs->cur + 1) % kSlots;
     }
@@ -273,7 +305,7 @@ int hvd_hasher_acquire_n(hvd_hasher* hs, int64_t want, uint8_t** out_frames, int
     if (want < 1) return hvd::api_fail(HVD_ERR_ARG, "want must be at least 1");
     if (int rc = hvd_hasher_acquire(hs, out_frames)) return rc;
     const Slot& s = hs->slot[hs->cur];
-    *out_n = hs->acquired_n = std::min<int64_t>(want, hs->batch - s.filled);
+    *out_n = hs->acquired_n = std::min<int64_t>(want, hs->limit - s.filled);
     return HVD_OK;
 }
 
@@ -286,7 +318,7 @@ int hvd_hasher_commit_n(hvd_hasher* hs, int64_t n) {
     if (int rc = hvd::api_bind_device()) return rc;
     hs->acquired = false;
     s.filled += n;
-    if (s.filled == hs->batch) {
+    if (s.filled >= hs->limit) {
         if (int rc = submit(hs, s)) return rc;
         hs->cur = (hs->cur + 1) % kSlots;
     }
@@ -299,7 +331,10 @@ int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame) {
     if (!hs || !frame) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher/frame");
     uint8_t* dst = nullptr;
     if (int rc = hvd_hasher_acquire(hs, &dst)) return rc;
-    g_copy_pool.copy(dst, frame, hs->frame_bytes, hs->copy_threads);
+    {
+        NsScope ns(g_ns_copy);
+        g_copy_pool.copy(dst, frame, hs->frame_bytes, hs->copy_threads);
+    }
     return hvd_hasher_commit(hs);
 }
 
@@ -345,6 +380,7 @@ int hvd_hasher_finish(hvd_hasher* hs, uint8_t* out_hashes, int32_t* out_quality,
     hs->hashes.clear();
     hs->quality.clear();
     hs->cur = 0;
+    hs->limit = first_limit(hs);  // the next video starts on an empty pipeline again
     return HVD_OK;
 }
 
