@@ -699,6 +699,11 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_mfma_auto_mid = (uint32_t)value;
         return HVD_OK;
     }
+    if (strcmp(key, "mfma_force_sel") == 0) {  // which 128 bits the first stage sees: -1 the probe's choice, 0 bits 0..127, 1 bits 128..255, 2 bits 0..63 + 192..255
+        if (value < -1 || value > 2) return fail(HVD_ERR_ARG, "mfma_force_sel: -1 (the probe chooses) or 0 | 1 | 2");
+        hvd::g_mfma_force_sel = value;
+        return HVD_OK;
+    }
     if (strcmp(key, "mfma_lds_pad") == 0) {  // occupancy experiments: bytes of unused dynamic LDS per workgroup of the FP4-MFMA kernels
         if (value < 0 || value > 65536) return fail(HVD_ERR_ARG, "mfma_lds_pad: 0..65536 bytes");
         hvd::g_mfma_lds_pad = (uint32_t)value;
@@ -774,13 +779,14 @@ int hvd_debug_get(const char* key, int* out_value) {
     if (int rc = need_ready()) return rc;
     // what the probe of the last auto-variant launch saw and chose: form id, survivors over bits 0..127 / 128..255,
     // 1 if the first stage ran on bits 128..255
-    const char* keys[4] = {"mfma_auto_form", "mfma_probe_survivors", "mfma_probe_survivors_hi", "mfma_auto_half"};
-    for (int k = 0; k < 4; ++k)
-        if (strcmp(key, keys[k]) == 0) {
+    // (word 4 is the probe's ticket; word 5 the survivors over bits 0..63 + 192..255, round 5)
+    const char* keys[6] = {"mfma_auto_form", "mfma_probe_survivors", "mfma_probe_survivors_hi", "mfma_auto_half", "", "mfma_probe_survivors_mix"};
+    for (int k = 0; k < 6; ++k)
+        if (keys[k][0] && strcmp(key, keys[k]) == 0) {
             uint32_t* sel = nullptr;
             HIP_TRY(hvd::mfma_select_buffer(t_ctx, &sel));
-            uint32_t v[4] = {0, 0, 0, 0};
-            HIP_TRY(hipMemcpyAsync(v, sel, 16, hipMemcpyDeviceToHost, g.stream));
+            uint32_t v[6] = {0, 0, 0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(v, sel, 24, hipMemcpyDeviceToHost, g.stream));
             HIP_TRY(hipStreamSynchronize(g.stream));
             *out_value = (int)v[k];
             return HVD_OK;

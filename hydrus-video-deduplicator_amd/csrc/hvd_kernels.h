@@ -32,6 +32,7 @@ bool allpairs_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32
 uint32_t fp4_rows_padded(uint32_t n);
 extern uint32_t g_mfma_col_chunk_max;
 extern uint32_t g_mfma_auto_mid, g_mfma_auto_mid_max_x100, g_mfma_queue_packed, g_mfma_lds_pad;
+extern int g_mfma_force_sel;
 extern uint32_t g_fp4_code;
 hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s);
 hipError_t launch_pack_fp4(const void* d_img, uint32_t n, void* d_db, hipStream_t s);  // image -> packed 32-byte hashes

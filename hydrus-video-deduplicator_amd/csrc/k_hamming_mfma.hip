@@ -414,6 +414,20 @@ __device__ __forceinline__ uint32_t sign_popc(const uint4& x, const uint4& y, ui
     return acc + __popc(x.x ^ y.x) + __popc(x.y ^ y.y) + __popc(x.z ^ y.z) + __popc(x.w ^ y.w);
 }
 
+// Which 128 bits the first stage sees (`sel`, the probe's choice, select[3]): 0 = bits 0..127, 1 = bits 128..255,
+// 2 = bits 0..63 and 192..255 (round 5: on config 5's frame hashes this mix lets 3x fewer unrelated pairs through than
+// either half, and a settled entry is what the pair-queue forms pay for). In 8-byte units of a packed hash (u0..u3) the
+// first stage sees {u0,u1} / {u2,u3} / {u0,u3}; the settlement's filter looks at the OTHER 128 bits, which are one
+// contiguous 16-byte block in every case: it starts at unit `ou` = 2 / 0 / 1. Only ou = 1 is not 16-byte aligned.
+__device__ __forceinline__ uint32_t other_unit_of(uint32_t sel) { return sel == 0u ? 2u : sel == 1u ? 0u : 1u; }
+template <class P>
+__device__ __forceinline__ uint4 other_block(P db, size_t hash, uint32_t ou) {
+    // two 8-byte loads from one line (adjacent: the memory pipeline merges what it can); P: a global or constant uint4*
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&db[hash * 2u]) + 2u * ou;
+    const uint2 a = *reinterpret_cast<const uint2*>(w), b = *reinterpret_cast<const uint2*>(w + 2);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+
 // Row of accumulator register r of a lane whose rows start at ib (C/D layout of the 32x32 MFMA).
 __device__ __forceinline__ uint32_t qrow_of(uint32_t ib, uint32_t r) { return ib + (r & 3u) + 8u * (r >> 2); }
 
@@ -522,11 +536,11 @@ __device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx,
 #if defined(HVD_K2_QABL) && HVD_K2_QABL == 6  // timing-only ablation: the call and nothing else
     return 0u;
 #endif
-    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
+    const uint32_t ou = ohw & 3u, wrows = ohw >> 8;  // first unit of the other 128 bits | rows per wave << 8
     {
         const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;  // rows beyond it are padding: never queued, never read
 #pragma unroll
-        for (uint32_t r = tid; r < kSuper * 8u; r += nthreads) rows_lds[r] = db_q[(size_t)min(row0 + r, last) * 2u + oh];
+        for (uint32_t r = tid; r < kSuper * 8u; r += nthreads) rows_lds[r] = other_block(db_q, (size_t)min(row0 + r, last), ou);
         __syncthreads();
     }
     constexpr int E = 3;
@@ -545,7 +559,7 @@ __device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx,
                 const uint2 e = *queue_entry(k, qc, qcap, &w);
                 // (bits 15, 12..14 are free: h and the wave ride along so that y and w need not be held)
                 ex[u] = e.x | ((e.y & 1u) << 15) | (w << 12);
-                col[u] = db_t[(size_t)(e.y >> 1) * 2u + oh];
+                col[u] = other_block(db_t, (size_t)(e.y >> 1), ou);
             }
         }
 #pragma unroll
@@ -585,7 +599,7 @@ __device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, ui
     const uint4* rows_lds = rows_generic;
     const uint32_t geom = geom_v, row0 = row0_v, ohw = other_half_v;
 #endif
-    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;  // other_half | rows per wave << 8
+    const uint32_t ou = ohw & 3u, wrows = ohw >> 8;  // first unit of the other 128 bits | rows per wave << 8
     const uint32_t waves = geom & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;
     const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
     const HitCtx c = load_ctx(ctx);
@@ -606,7 +620,7 @@ __device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, ui
             settle_pair(c, row0 + qrow_of(ibrel, r0 + q), j);
         }
         if (gm == 0u) continue;
-        const uint4 col = packed ? c.db_t[(size_t)j * 2u + oh] : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 col = packed ? other_block(c.db_t, (size_t)j, ou) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 1
         while (gm != 0u) {  // the groups nobody has looked at yet
             const uint32_t bit = 31u - (uint32_t)__clz((int)gm);
@@ -684,7 +698,7 @@ __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict_
 #if defined(HVD_K2_QABL) && HVD_K2_QABL == 6  // timing-only ablation: the call and nothing else
     return 0u;
 #endif
-    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;
+    const uint32_t ou = ohw & 3u, wrows = ohw >> 8;
     const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;
     constexpr int E = HVD_K2_QE;
     uint32_t left = 0;
@@ -704,14 +718,14 @@ __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict_
                 const uint2 e = *queue_entry(k, qc, qcap, &w);
                 ex[u] = e.x;
                 lanerel[u] = 4u * (e.y & 1u) + wrows * w;  // the lane's first row, relative to row0
-                col[u] = db_t[(size_t)(e.y >> 1) * 2u + oh];
+                col[u] = other_block(db_t, (size_t)(e.y >> 1), ou);
             }
         }
         // the workgroup's own rows (coalesced) are requested BEHIND the first round's column gathers, so that the two memory
         // round trips of a settlement run side by side
         if (!staged) {
 #pragma unroll
-            for (uint32_t r = tid; r < kSuper * 8u; r += nthreads) rows_lds[r] = db_q[(size_t)min(row0 + r, last) * 2u + oh];
+            for (uint32_t r = tid; r < kSuper * 8u; r += nthreads) rows_lds[r] = other_block(db_q, (size_t)min(row0 + r, last), ou);
             __syncthreads();
             staged = true;
         }
@@ -742,15 +756,16 @@ __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict_
                     if (__builtin_expect(p4 != 0u, 0)) {
                         uint32_t w2;
                         const uint32_t j = queue_entry(k, qc, qcap, &w2)->y >> 1;
-                        const uint4 cf = db_t[(size_t)j * 2u + (oh ^ 1u)];
+                        // (all 256 bits from the packed hashes: the first stage's 128 are not one block for every selection)
+                        const uint4 c0 = db_t[(size_t)j * 2u], c1 = db_t[(size_t)j * 2u + 1u];
                         uint32_t hit = 0;
 #pragma unroll 1
                         while (p4 != 0u) {
                             const uint32_t r = (uint32_t)__ffs((int)p4) - 1u;
                             p4 &= p4 - 1u;
                             const uint32_t rowrel = ib + 8u * c + ((r + (HVD_K2_QROT ? tid : 0u)) & 3u);
-                            const uint4 rf = db_q[(size_t)min(row0 + rowrel, last) * 2u + (oh ^ 1u)];
-                            if (sign_popc(rf, cf, sign_popc(rows_lds[rowrel], col[u], 0u)) <= max_dist) hit = 1u;
+                            const size_t ri = (size_t)min(row0 + rowrel, last);
+                            if (sign_popc(db_q[ri * 2u], c0, sign_popc(db_q[ri * 2u + 1u], c1, 0u)) <= max_dist) hit = 1u;
                         }
                         p4 = hit;
                     }
@@ -778,7 +793,7 @@ __device__ __noinline__ void settle_marked_panel_wg(const HitCtx* __restrict__ c
     const uint32_t geom = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom_v);
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
     const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
-    const uint32_t oh = ohw & 1u, wrows = ohw >> 8;
+    const uint32_t ou = ohw & 3u, wrows = ohw >> 8;
     const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = (geom >> 20) & 7u, nthreads = 64u * waves;
     const uint32_t qshift = qg >> 1, nrows = 16u >> qshift, top = tiles * qg - 1u;
     const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
@@ -792,7 +807,7 @@ __device__ __noinline__ void settle_marked_panel_wg(const HitCtx* __restrict__ c
         uint32_t m = e.x;
         if (m == 0u) continue;
         const uint32_t lanerel = 4u * (e.y & 1u) + wrows * w, j = e.y >> 1;
-        const uint4 col = packed ? c.db_t[(size_t)j * 2u + oh] : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 col = packed ? other_block(c.db_t, (size_t)j, ou) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 1
         while (m != 0u) {
             const uint32_t bit = 31u - (uint32_t)__clz((int)m);
@@ -853,7 +868,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
                                                           uint32_t max_dist, uint32_t col_chunk, uint32_t rank,
                                                           uint32_t world, const uint4* __restrict__ img_q, float scale2,
                                                           const HitCtx* __restrict__ ctx,
-                                                          const uint32_t* __restrict__ select, uint32_t select_id) {
+                                                          const uint32_t* __restrict__ select, uint32_t select_id, uint32_t sel_arg) {
     static_assert(S1 == 2 || S1 == 4, "first stage = 128 or 256 bits");
     static_assert(NBR >= S1 && (NBR == 2 || NBR == 4), "register-resident k-steps");
     static_assert(!QUEUE || (NBR == 2 && S1 == 2 && TILES <= 8), "the pair queue belongs to the 128-bit fetch form");
@@ -872,7 +887,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
     // Which 128 bits the first stage sees is the probe's choice too (select[3]): the image keeps bits 0..127 in chunks
     // 0..3 and bits 128..255 in chunks 4..7, so "the other half first" is chunk ^ 4 in every fragment address -- a
     // launch-uniform XOR into the slot swizzle. The full-distance paths sum over all eight chunks and do not care.
-    const uint32_t selx = select != nullptr ? (select[3] & 1u) << 2 : 0u;
+    // Round 5: a third selection, bits 0..63 + 192..255 (other_unit_of, above): k-step s reads chunks 2s, 2s+1 XOR selx_s with
+    // selx_0 = selx_2, selx_1 = selx_3 in {0, 4}, so that the four steps still cover every chunk once.
+    const uint32_t sel = select != nullptr ? (select[3] & 3u) : sel_arg;
+    const uint32_t selx0 = sel == 1u ? 4u : 0u, selx1 = sel != 0u ? 4u : 0u;
 
     const uint32_t rb = blockIdx.x, cb = blockIdx.y;
     const uint32_t row0 = rb * ROWS;
@@ -895,7 +913,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
         const uint32_t hash = wrow0 + 32u * t + li;  // < n_pad by construction
 #pragma unroll
         for (int s = 0; s < NBR; ++s) {
-            const uint4 q = imgq[(size_t)hash * 8u + (img_slot(hash, 2u * s + h) ^ selx)];
+            const uint4 q = imgq[(size_t)hash * 8u + (img_slot(hash, 2u * s + h) ^ ((s & 1) ? selx1 : selx0))];
             // negated: flip the sign bit of every e2m1 nibble (see or16_bits)
             const uint32_t fl = kSign ? 0x88888888u : 0u;
             a[t][s] = v4i{(int)(q.x ^ fl), (int)(q.y ^ fl), (int)(q.z ^ fl), (int)(q.w ^ fl)};
@@ -940,15 +958,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
         for (uint32_t p = 0; p < kSuper / 32; ++p) {
             const uint32_t cl = 32u * p + li;  // candidate index inside the super-panel
             const uint4* base = &panel[cl * 8u];
-            const uint32_t sw = ((cl >> 1) & 7u) ^ selx;  // jsp is a multiple of 128: same swizzle as the global index
+            const uint32_t swb = (cl >> 1) & 7u;  // jsp is a multiple of 128: same swizzle as the global index
+            const uint32_t sw0 = swb ^ selx0, sw1 = swb ^ selx1;  // k-steps 0, 2 / 1, 3 (the selection, above)
             v4i b[S1];
 #pragma unroll
-            for (int s = 0; s < S1; ++s) b[s] = as_v4i(base[(2u * s + h) ^ sw]);
+            for (int s = 0; s < S1; ++s) b[s] = as_v4i(base[(2u * s + h) ^ ((s & 1) ? sw1 : sw0)]);
             // register cascade form: the 192-bit step's B fragment is read WITH the panel's first two, so that a first-stage
             // survivor goes straight to its MFMA instead of waiting out an LDS round trip first (on frame hashes most
             // panels have one; same-box A/B on structured hashes: -2.5 %)
             v4i b192 = b[0];
-            if constexpr (NBR == 4 && S1 == 2 && kCascade) b192 = as_v4i(base[(4u + h) ^ sw]);
+            if constexpr (NBR == 4 && S1 == 2 && kCascade) b192 = as_v4i(base[(4u + h) ^ sw0]);
 
             // two accumulator sets: the MFMAs of tile t+1 are issued before the max tree of tile t
             if constexpr (QUEUE >= 2) {
@@ -1099,11 +1118,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
                         if (kCascade) {
                             acc = mfma_fp4(a[t][2], b192, acc);
                             if (!stage192_hit(acc)) return;
-                            acc = mfma_fp4(a[t][3], as_v4i(base[(6u + h) ^ sw]), acc);
+                            acc = mfma_fp4(a[t][3], as_v4i(base[(6u + h) ^ sw1]), acc);
                         } else {
                             v4i b2[2];
 #pragma unroll
-                            for (int s = 0; s < 2; ++s) b2[s] = as_v4i(base[(2u * (s + 2) + h) ^ sw]);
+                            for (int s = 0; s < 2; ++s) b2[s] = as_v4i(base[(2u * (s + 2) + h) ^ (s ? sw1 : sw0)]);
                             acc = tile_dot<0, 2>(&a[t][2], b2, acc);
                         }
                         if (!stage2_hit(acc)) return;
@@ -1153,11 +1172,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
 #if !(defined(HVD_K2_QABL) && HVD_K2_QABL == 3)  // 3 = pushed entries are dropped instead of settled
                 const uint32_t GEOM = (uint32_t)WAVES | ((uint32_t)TILES << 4) | (QCAP << 8) | ((uint32_t)QG << 20) | (par << 24);
                 if constexpr (QUEUE >= 2) {
-                    const uint32_t left = drain_filter_panel_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
-                    if (__builtin_expect(__any(left != 0u), 0)) settle_marked_panel_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                    const uint32_t left = drain_filter_panel_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
+                    if (__builtin_expect(__any(left != 0u), 0)) settle_marked_panel_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
                 } else {
-                    const uint32_t left = drain_filter_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
-                    if (__builtin_expect(__any(left != 0u), 0)) settle_marked_wg(ctx, GEOM, row0, (selx ? 0u : 1u) | (WROWS << 8), wave * 64u + lane, free_panel);
+                    const uint32_t left = drain_filter_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
+                    if (__builtin_expect(__any(left != 0u), 0)) settle_marked_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
                 }
 #endif
                 qidx = wave * QCAP;
@@ -1204,8 +1223,9 @@ struct ProbeRule {  // survivors among `pairs` sampled pairs -> form (probe_deci
     uint64_t pairs;
     uint32_t pairs_per_step, id_rare, id_mid, id_often;
     float mid_max_per_tile;
+    int force_sel;  // >= 0: the first-stage selection is not the probe's to choose (hvd_debug_set "mfma_force_sel": tests, A/B runs)
 };
-__device__ void probe_decide(uint32_t* __restrict__ select, uint32_t lo, uint32_t hi, const ProbeRule& rule);
+__device__ void probe_decide(uint32_t* __restrict__ select, uint32_t lo, uint32_t hi, uint32_t mix, const ProbeRule& rule);
 
 __global__ __launch_bounds__(256) void k_prefilter_probe(const uint4* __restrict__ img_q, uint32_t nq,
                                                          const uint4* __restrict__ img_t, uint32_t nt, uint32_t max_dist,
@@ -1229,38 +1249,45 @@ __global__ __launch_bounds__(256) void k_prefilter_probe(const uint4* __restrict
     __syncthreads();
     const uint32_t c0 = blockIdx.y * kProbeColsPerWg;
     const uint32_t m = c0 >= ncols ? 0u : min(kProbeColsPerWg, ncols - c0);
-    uint32_t cnt = 0, cnt_hi = 0;  // survivors of a first stage over bits 0..127 / over bits 128..255
+    // survivors of a first stage over bits 0..127 / over bits 128..255 / over bits 0..63 + 192..255 (per 64-bit unit u0..u3:
+    // the same 32 popcounts as before, three sums instead of two)
+    uint32_t cnt = 0, cnt_hi = 0, cnt_mix = 0;
     for (uint32_t k = 0; k < m; ++k) {
-        const uint32_t d = sign_popc(q[0], cols[k][0], sign_popc(q[1], cols[k][1], sign_popc(q[2], cols[k][2], sign_popc(q[3], cols[k][3], 0u))));
-        const uint32_t d_hi = sign_popc(q[4], cols[k][4], sign_popc(q[5], cols[k][5], sign_popc(q[6], cols[k][6], sign_popc(q[7], cols[k][7], 0u))));
-        cnt += d <= max_dist ? 1u : 0u;
-        cnt_hi += d_hi <= max_dist ? 1u : 0u;
+        const uint32_t u0 = sign_popc(q[0], cols[k][0], sign_popc(q[1], cols[k][1], 0u)), u1 = sign_popc(q[2], cols[k][2], sign_popc(q[3], cols[k][3], 0u));
+        const uint32_t u2 = sign_popc(q[4], cols[k][4], sign_popc(q[5], cols[k][5], 0u)), u3 = sign_popc(q[6], cols[k][6], sign_popc(q[7], cols[k][7], 0u));
+        cnt += u0 + u1 <= max_dist ? 1u : 0u;
+        cnt_hi += u2 + u3 <= max_dist ? 1u : 0u;
+        cnt_mix += u0 + u3 <= max_dist ? 1u : 0u;
     }
-    if (r >= rows) cnt = cnt_hi = 0;
+    if (r >= rows) cnt = cnt_hi = cnt_mix = 0;
     for (int off = 32; off > 0; off >>= 1) {
         cnt += __shfl_down(cnt, off);
         cnt_hi += __shfl_down(cnt_hi, off);
+        cnt_mix += __shfl_down(cnt_mix, off);
     }
     // one pair of atomics per WORKGROUP (same-address device atomics take ~8 ns each: per wave they were 65 us of a probe over
     // frame hashes), and the workgroup that finishes last turns the two sums into the decision -- one launch less per pass (a
     // one-lane kernel costs ~5 us plus the gap in front of it). No fence anywhere: the sums travel in atomics, which are
     // performed at the memory side, and a workgroup takes its ticket (select[4], zeroed by k_set_hit_ctx with the rest) only
     // after its own additions have RETURNED.
-    __shared__ uint32_t part[2][4];
+    __shared__ uint32_t part[3][4];
     if ((threadIdx.x & 63u) == 0u) {
         part[0][threadIdx.x >> 6] = cnt;
         part[1][threadIdx.x >> 6] = cnt_hi;
+        part[2][threadIdx.x >> 6] = cnt_mix;
     }
     __syncthreads();
     if (threadIdx.x == 0u) {
         const uint32_t c_lo = part[0][0] + part[0][1] + part[0][2] + part[0][3];
         const uint32_t c_hi = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        const uint32_t c_mix = part[2][0] + part[2][1] + part[2][2] + part[2][3];
         uint32_t seen = 0;
         if (c_lo) seen += atomicAdd(&select[1], c_lo);
         if (c_hi) seen += atomicAdd(&select[2], c_hi);
+        if (c_mix) seen += atomicAdd(&select[5], c_mix);
         asm volatile("" ::"v"(seen));  // (the returning form, and its result waited for)
         if (atomicAdd(&select[4], 1u) == gridDim.x * gridDim.y - 1u)
-            probe_decide(select, atomicAdd(&select[1], 0u), atomicAdd(&select[2], 0u), rule);
+            probe_decide(select, atomicAdd(&select[1], 0u), atomicAdd(&select[2], 0u), atomicAdd(&select[5], 0u), rule);
     }
 }
 
@@ -1272,7 +1299,7 @@ __global__ void k_set_hit_ctx(HitCtx* __restrict__ dst, const HitCtx src, uint32
     *dst = src;
     if (select != nullptr) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) select[k] = 0u;
+        for (int k = 0; k < 6; ++k) select[k] = 0u;
     }
 }
 
@@ -1281,12 +1308,25 @@ __global__ void k_set_hit_ctx(HitCtx* __restrict__ dst, const HitCtx src, uint32
 // entry per surviving lane and nothing on the matrix pipe: right for real frame hashes, whose first 128 bits agree within the
 // tolerance for ~2e-4 of unrelated pairs. The register form (id_often) pays one MFMA per surviving tile however many pairs
 // survive in it: right when most tiles hold several survivors (a library whose hashes barely differ in either half).
-__device__ void probe_decide(uint32_t* __restrict__ select, uint32_t lo, uint32_t hi, const ProbeRule& rule) {
-    // first the half: the one whose 128 bits let fewer unrelated pairs through (ties and near-ties stay with bits 0..127,
-    // so that uniform data always runs the same configuration); then the form, from that half's rate
-    const bool use_hi = (double)hi * 1.25 < (double)lo;
-    select[3] = use_hi ? 1u : 0u;
-    const double rate = rule.pairs ? (double)(use_hi ? hi : lo) / (double)rule.pairs : 0.0;
+__device__ void probe_decide(uint32_t* __restrict__ select, uint32_t lo, uint32_t hi, uint32_t mix, const ProbeRule& rule) {
+    // first the selection: the 128 bits that let the fewest unrelated pairs through (ties and near-ties stay with bits 0..127,
+    // so that uniform data always runs the same configuration; an alternative has to be 20 % better than what it replaces);
+    // then the form, from that selection's rate
+    uint32_t sel = 0u, best = lo;
+    if ((double)hi * 1.25 < (double)best) {
+        sel = 1u;
+        best = hi;
+    }
+    if ((double)mix * 1.25 < (double)best) {
+        sel = 2u;
+        best = mix;
+    }
+    if (rule.force_sel >= 0) {
+        sel = (uint32_t)rule.force_sel;
+        best = sel == 0u ? lo : sel == 1u ? hi : mix;
+    }
+    select[3] = sel;
+    const double rate = rule.pairs ? (double)best / (double)rule.pairs : 0.0;
     uint32_t form = rule.id_rare;
     if (rate * (double)rule.pairs_per_step > 0.01)
         form = (rule.id_mid != 0u && rate * 1024.0 <= (double)rule.mid_max_per_tile) ? rule.id_mid : rule.id_often;
@@ -1322,6 +1362,7 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
 uint32_t g_mfma_lds_pad = 0;  // occupancy experiments: unused dynamic LDS per workgroup (hvd_debug_set "mfma_lds_pad")
 uint32_t g_mfma_queue_packed = 1;  // 0: the pair queue settles from the FP4 images even when packed hashes are at hand (tests)
 uint32_t g_mfma_auto_mid = 18;
+int g_mfma_force_sel = -1;  // hvd_debug_set "mfma_force_sel": -1 the probe chooses (explicit forms: bits 0..127); 0 | 1 | 2 forced
 uint32_t g_mfma_auto_mid_max_x100 = 500;  // (scripts/gpu_k2_rate_sweep.py: the panel-mark queue takes 0.61-0.67 of the register form's time
                                           // at 1-2.7 survivors per tile, 0.79 at 4, 0.88 at 5.3, 1.23 at 8; round 4's first queue form, 15,
                                           // won up to ~1 and the boundary was 1.3)
@@ -1433,11 +1474,11 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
     if (rect)
         hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE, WAVES>), grid, dim3(64 * WAVES), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
-                           select_id);
+                           select_id, (uint32_t)(g_mfma_force_sel > 0 ? g_mfma_force_sel : 0));
     else
         hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE, WAVES>), grid, dim3(64 * WAVES), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)nullptr, fp4_scale2(), ctx, d_select,
-                           select_id);
+                           select_id, (uint32_t)(g_mfma_force_sel > 0 ? g_mfma_force_sel : 0));
     return hipGetLastError();
 }
 
@@ -1460,8 +1501,8 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
     }
 }
 
-// select[0] = form to run, select[1] / select[2] = first-stage survivors the probe counted over bits 0..127 / 128..255,
-// select[3] = 1: the first stage runs on bits 128..255. One buffer per CONTEXT of the library (a context = one stream on one
+// select[0] = form to run, select[1] / select[2] / select[5] = first-stage survivors the probe counted over bits 0..127 /
+// 128..255 / 0..63 + 192..255, select[3] = the selection the first stage runs on (0 / 1 / 2), select[4] = the probe's ticket. One buffer per CONTEXT of the library (a context = one stream on one
 // device; a group may hold two contexts on one device, whose passes run concurrently on their own streams).
 constexpr int kMaxSelect = 16;
 static uint32_t* g_select[kMaxSelect] = {};
@@ -1515,7 +1556,7 @@ static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rec
     const uint32_t rows = nrows < kProbeRows ? nrows : kProbeRows, cols = a.n < kProbeCols ? a.n : kProbeCols;
     // (the pair queue keeps (column << 1 | half) in 32 bits)
     const uint32_t mid = fp4_rows_padded(a.n) < (1u << 31) ? g_mfma_auto_mid : 0u;
-    const ProbeRule rule = {(uint64_t)rows * cols, 8192u, 9u, mid, 12u, 0.01f * (float)g_mfma_auto_mid_max_x100};
+    const ProbeRule rule = {(uint64_t)rows * cols, 8192u, 9u, mid, 12u, 0.01f * (float)g_mfma_auto_mid_max_x100, g_mfma_force_sel};
     hipLaunchKernelGGL(k_prefilter_probe, dim3((rows + 255u) / 256u, (cols + kProbeColsPerWg - 1u) / kProbeColsPerWg), dim3(256), 0, s,
                        (const uint4*)(rect ? d_img_q : d_img), nrows, (const uint4*)d_img, a.n, a.max_dist, sel, rule);
     e = launch_variant(9, a, d_img, rect, d_img_q, nq, d_group_t, sel, s, false);

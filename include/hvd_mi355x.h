@@ -213,6 +213,8 @@ int hvd_get_pdq_dct_mode(void);
  *   "mfma_auto_mid" 0|15..19, "mfma_auto_mid_max_x100" n   (auto variant: the pair-queue form it may pick -- 18 -- and the survivor
  *                                                           density per 1024-pair tile, x 0.01, up to which it does -- 500)
  *   "mfma_queue_packed" 0|1, "mfma_lds_pad" bytes          (pair queue settles from the FP4 images only; occupancy experiments)
+ *   "mfma_force_sel" -1|0|1|2                              (which 128 bits the first stage sees: the probe's choice | bits 0..127 |
+ *                                                           128..255 | 0..63 + 192..255)
  *   "pdq_hash_grid" n, "pdq_hash_prefetch" 0|1             (64x64 hash kernel: forced grid; next frame fetched ahead, off)
  *   "vmatch_exchange" 0|1|2                                (key exchange of the video search: iff world > 1 | always | never)
  *   "vmatch_slots_log2" 0|4..30                            (initial size of the video-reduction tables; tests the regrowth)
@@ -220,8 +222,9 @@ int hvd_get_pdq_dct_mode(void);
  * Unknown keys and out-of-range values return HVD_ERR_ARG. */
 int hvd_debug_set(const char* key, int value);
 /* "mfma_auto_form": the form (9, 18 or 12; 15..19 if "mfma_auto_mid" says so) the last auto-variant launch ran;
- * "mfma_probe_survivors" / "mfma_probe_survivors_hi": what its probe counted over bits 0..127 / 128..255; "mfma_auto_half":
- * 1 if the first stage ran on bits 128..255. Synchronises the library stream.
+ * "mfma_probe_survivors" / "mfma_probe_survivors_hi" / "mfma_probe_survivors_mix": what its probe counted over bits 0..127 /
+ * 128..255 / 0..63 + 192..255; "mfma_auto_half": the selection the first stage ran on (0 / 1 / 2 in that order).
+ * Synchronises the library stream.
  * "vmatch_us_local" / "vmatch_us_exchange" / "vmatch_us_fold": host microseconds of the three phases of the last video-level
  * search on the calling thread's context (local: packed hashes, probe, all-pairs pass, key set; exchange: agreement words,
  * all-gather of the key lists, merged set -- 0 at world 1; fold: keys -> pair map). "copy_nt": 0 | 2 | 3 = plain memcpy |

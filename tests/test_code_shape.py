@@ -143,7 +143,8 @@ def test_every_allpairs_instantiation_is_in_the_table(shapes):
 
 def test_probe_and_image_kernels(shapes):
     m = shapes["mfma"]
-    assert waves_per_simd(m["k_prefilter_probe"]["vgpr"]) >= 4 and m["k_prefilter_probe"]["vgpr_spill"] == 0
+    # (round 5: a third survivor count -- 137 VGPRs = 3 waves per SIMD; capped at 128 it spills 17, and the probe is 0.3 % of a pass)
+    assert waves_per_simd(m["k_prefilter_probe"]["vgpr"]) >= 3 and m["k_prefilter_probe"]["vgpr_spill"] == 0
     for name in ("k_expand_fp4", "k_pack_fp4"):
         assert waves_per_simd(m[name]["vgpr"]) == 8 and m[name]["lds"] == 0 and m[name]["vgpr_spill"] == 0
 

@@ -244,3 +244,79 @@ def test_gpu_test_process_runs_on_the_system_rocm_not_on_torchs_bundle(gpu):
     info = gpu.runtime_info()
     assert "/torch/" not in info["librccl_path"] and "/torch/" not in info["libamdhip64_path"], info
     assert info["rccl_version"] == info["rccl_built_against"], info
+
+
+# ------------------------------------------------------------------ K2: the first stage's third selection (bits 0..63 + 192..255)
+
+def _forced_sel(gpu, value):
+    gpu.check(gpu.load().hvd_debug_set(b"mfma_force_sel", value))
+
+
+@pytest.mark.parametrize("sel", [0, 1, 2])
+def test_k2_every_form_on_every_first_stage_selection(gpu, hvd, oracle, sel):
+    """Which 128 bits the first stage sees must not change a single record: every MFMA form with the selection forced --
+    bits 0..127, 128..255 and (round 5) 0..63 + 192..255 -- on a DB whose planted distances straddle the tolerance in every
+    split between the two sides (all of a pair's flips in the first-stage bits, all in the other bits, even mixes)."""
+    n = 30_000
+    rng = np.random.default_rng(90 + sel)
+    db, _ = hvd.synth.hash_db(n, seed=91, plant_fraction=0.0)
+    src = rng.choice(n // 2, 1500, replace=False)
+    dst = n // 2 + rng.choice(n // 2, 1500, replace=False)
+    units = {0: (0, 1), 1: (2, 3), 2: (0, 3)}[sel]  # the 64-bit units the first stage sees
+    other = tuple(u for u in range(4) if u not in units)
+    for k, (s_, d_) in enumerate(zip(src, dst)):
+        row = db[s_].copy()
+        total = 29 + k % 6                      # 29 .. 34 flips: both sides of the tolerance 31
+        in_first = (0, total, total // 2, total - 1, 1, 31, 32)[k % 7]
+        in_first = min(in_first, total)
+        for side, cnt in ((units, in_first), (other, total - in_first)):
+            bits = np.concatenate([np.arange(64 * u, 64 * u + 64) for u in side])
+            for b in rng.choice(bits, cnt, replace=False):
+                row[b >> 3] ^= np.uint8(1 << (b & 7))
+        db[d_] = row
+    want = oracle.allpairs(db, 31, num_threads=8)
+    assert 500 < len(want) < 1500
+    d_db = gpu.DeviceBuffer.from_array(db)
+    try:
+        _forced_sel(gpu, sel)
+        for v in (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
+            got = hvd.multigpu.sharded_allpairs(d_db.ptr, n, 0, 1, None, variant=v)
+            _pairs_equal(got, want, f"variant {v}, selection {sel}")
+        if sel:  # the auto variant reports the forced selection
+            half = C.c_int(0)
+            gpu.check(gpu.load().hvd_debug_get(b"mfma_auto_half", C.byref(half)))
+            assert half.value == sel
+        # video mode and the rectangular form through the same selection
+        fr, off, _ = hvd.synth.video_hashes(400, seed=92, frames_per_video=(1, 40), copy_fraction=0.2)
+        assert np.array_equal(hvd.match_videos(fr, off, 31), oracle.match_videos(fr, off, 31, num_threads=8))
+    finally:
+        _forced_sel(gpu, -1)
+        d_db.free()
+
+
+def test_k2_probe_picks_the_mixed_selection_when_the_middle_bits_are_degenerate(gpu, hvd, oracle):
+    """Bits 64..191 nearly constant across the DB: both halves contain 64 degenerate bits and let many unrelated pairs
+    through, bits 0..63 + 192..255 do not -- the probe must put the first stage there, and the pair list stays the oracle's."""
+    lib = gpu.load()
+    n = 60_000
+    rng = np.random.default_rng(93)
+    db, _ = hvd.synth.hash_db(n, seed=94, plant_fraction=0.01)
+    proto = rng.integers(0, 256, 16, dtype=np.uint8)
+    mid = np.tile(proto, (n, 1))
+    flips = rng.integers(0, 128, (n, 3))          # three random flips per hash inside the degenerate 128 bits
+    for c in range(3):
+        np.bitwise_xor.at(mid, (np.arange(n), flips[:, c] >> 3), (1 << (flips[:, c] & 7)).astype(np.uint8))
+    db[:, 8:24] = mid
+    d_db = gpu.DeviceBuffer.from_array(db)
+    try:
+        got = hvd.multigpu.sharded_allpairs(d_db.ptr, n, 0, 1, None, variant=13, cap=1 << 22)
+        vals = {}
+        for key in (b"mfma_auto_half", b"mfma_probe_survivors", b"mfma_probe_survivors_hi", b"mfma_probe_survivors_mix", b"mfma_auto_form"):
+            v = C.c_int(0)
+            gpu.check(lib.hvd_debug_get(key, C.byref(v)))
+            vals[key.decode()] = v.value
+        assert vals["mfma_auto_half"] == 2, vals
+        assert vals["mfma_probe_survivors_mix"] * 100 < min(vals["mfma_probe_survivors"], vals["mfma_probe_survivors_hi"]), vals
+        _pairs_equal(got, oracle.allpairs(db, 31, num_threads=8, cap=1 << 22), "auto variant on the mixed selection")
+    finally:
+        d_db.free()
