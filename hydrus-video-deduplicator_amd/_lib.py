@@ -214,6 +214,11 @@ def ensure() -> C.CDLL:
 def shutdown() -> None:
     global _inited_device
     if _lib is not None and _inited_device is not None:
+        import sys
+
+        pl = sys.modules.get(__package__ + ".pipeline")
+        if pl is not None:
+            pl.release_record_buffers()  # (device memory of the old binding: must not be handed out after a re-init)
         check(_lib.hvd_shutdown())
         _inited_device = None
 

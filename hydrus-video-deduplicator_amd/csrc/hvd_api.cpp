@@ -1407,6 +1407,7 @@ int vmatch_build(const VmArgs& v) {
         a.d_db = d_bits_t;
         a.d_db_q = d_bits_q;
         a.n = v.nt;
+        a.sync_decide = true;  // (this call waits for its result anyway)
         a.d_group = v.rect ? v.d_excl_q : v.d_vid_q;  // symmetric: frames of one video never match each other
         a.max_dist = (uint32_t)v.max_dist;
         a.rank = (uint32_t)v.rank;

@@ -23,6 +23,11 @@ struct AllPairsArgs {
     uint32_t col_chunk;      // 0 = pick automatically
     int ctx_id = 0;          // the caller's context: selects the FP4-MFMA forms' per-context select/context words
     VideoSink sink = {nullptr, 0, nullptr, nullptr, nullptr};  // FP4-MFMA form only: reduce to video level (K3)
+    // auto variant only. false: probe and all candidate forms are enqueued, the unchosen ones return at once -- no host
+    // synchronisation (the device-resident entry points promise that). true (callers that wait for the result anyway: the video
+    // search, the host-buffer entry): the host reads the probe's decision and launches the chosen form alone -- on a 2.9 M-frame
+    // library the two empty launches are ~1e6 workgroups each, 0.2 + 0.4 ms.
+    bool sync_decide = false;
 };
 
 hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s);

@@ -422,8 +422,10 @@ __device__ __forceinline__ uint32_t sign_popc(const uint4& x, const uint4& y, ui
 __device__ __forceinline__ uint32_t other_unit_of(uint32_t sel) { return sel == 0u ? 2u : sel == 1u ? 0u : 1u; }
 template <class P>
 __device__ __forceinline__ uint4 other_block(P db, size_t hash, uint32_t ou) {
-    // two 8-byte loads from one line (adjacent: the memory pipeline merges what it can); P: a global or constant uint4*
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(&db[hash * 2u]) + 2u * ou;
+    // ou is launch-uniform: the aligned cases keep their single 16-byte load (a scalar branch), the mix takes two 8-byte loads
+    // from one line; P: a global or constant uint4*
+    if ((ou & 1u) == 0u) return db[hash * 2u + (ou >> 1)];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&db[hash * 2u]) + 2u;
     const uint2 a = *reinterpret_cast<const uint2*>(w), b = *reinterpret_cast<const uint2*>(w + 2);
     return make_uint4(a.x, a.y, b.x, b.y);
 }
@@ -1559,6 +1561,14 @@ static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rec
     const ProbeRule rule = {(uint64_t)rows * cols, 8192u, 9u, mid, 12u, 0.01f * (float)g_mfma_auto_mid_max_x100, g_mfma_force_sel};
     hipLaunchKernelGGL(k_prefilter_probe, dim3((rows + 255u) / 256u, (cols + kProbeColsPerWg - 1u) / kProbeColsPerWg), dim3(256), 0, s,
                        (const uint4*)(rect ? d_img_q : d_img), nrows, (const uint4*)d_img, a.n, a.max_dist, sel, rule);
+    if (a.sync_decide) {
+        uint32_t form = 0;
+        e = hipMemcpyAsync(&form, sel, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        if (form != 9u && form != 12u && form != mid) return hipErrorUnknown;  // (the probe writes one of its rule's three ids)
+        return launch_variant((int)form, a, d_img, rect, d_img_q, nq, d_group_t, sel, s, false);
+    }
     e = launch_variant(9, a, d_img, rect, d_img_q, nq, d_group_t, sel, s, false);
     if (e != hipSuccess) return e;
     if (mid) {

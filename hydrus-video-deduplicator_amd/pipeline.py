@@ -151,30 +151,49 @@ class DeviceLibrary:
         if max_dist < 0 or self.n_frames < 2:
             return np.zeros(0, dtype=VMATCH_DTYPE)
         cap = max(4096, self.n_videos) if cap is None else int(cap)
-        d_cnt = DeviceBuffer(8)
-        d_out = DeviceBuffer(16 * cap)
-        try:
-            _lib.check(lib.hvd_dev_vpdq_match_videos(self.image().ptr, self.n_frames, self.d_video.ptr, max_dist,
-                                                     rank, world, d_out.ptr, cap, d_cnt.ptr))
+        # the record buffer is kept from call to call (per context): two hipMalloc / hipFree round trips inside every search were
+        # ~1 % of a 50 000-video pass during which the GPU did nothing
+        d_out, d_cnt, _ = _record_buffers(cap)  # (the call is told `cap` as asked, whatever the kept buffer would hold)
+        _lib.check(lib.hvd_dev_vpdq_match_videos(self.image().ptr, self.n_frames, self.d_video.ptr, max_dist,
+                                                 rank, world, d_out.ptr, cap, d_cnt.ptr))
+        cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+        if cnt > cap:  # more video pairs than room: ONLY the emit is repeated (no second O(n^2) pass, no second
+            # key exchange that every rank would have to enter in lock-step)
+            cap = cnt
+            d_out, d_cnt, _ = _record_buffers(cap)
+            _lib.check(lib.hvd_dev_vpdq_emit_again(d_out.ptr, cap, d_cnt.ptr))
             cnt = int(d_cnt.to_array(np.uint64, 1)[0])
-            if cnt > cap:  # more video pairs than room: ONLY the emit is repeated (no second O(n^2) pass, no second
-                cap = cnt  # key exchange that every rank would have to enter in lock-step)
-                d_out.free()
-                d_out = DeviceBuffer(16 * cap)
-                _lib.check(lib.hvd_dev_vpdq_emit_again(d_out.ptr, cap, d_cnt.ptr))
-                cnt = int(d_cnt.to_array(np.uint64, 1)[0])
-                assert cnt <= cap
-            recs = d_out.to_array(VMATCH_DTYPE, cnt)
-            return recs[np.lexsort((recs["b"], recs["a"]))]
-        finally:
-            d_out.free()
-            d_cnt.free()
+            assert cnt <= cap
+        recs = d_out.to_array(VMATCH_DTYPE, cnt)
+        return recs[np.argsort((recs["a"].astype(np.uint64) << np.uint64(32)) | recs["b"].astype(np.uint64), kind="stable")]
 
     def free(self) -> None:
         for b in (self.d_hashes, self.d_offsets, self.d_video, self.d_img):
             if b is not None:
                 b.free()
         self.d_img = None
+
+
+_RECORD_BUFFERS: dict = {}  # context index -> (d_out, d_cnt, cap): grow-only, released by release_record_buffers()
+
+
+def _record_buffers(cap: int):
+    ctx = _lib.load().hvd_get_context()
+    have = _RECORD_BUFFERS.get(ctx)
+    if have is None or have[2] < cap or have[0].ptr is None:
+        if have is not None:
+            have[0].free()
+            have[1].free()
+        have = (DeviceBuffer(16 * cap), DeviceBuffer(8), cap)
+        _RECORD_BUFFERS[ctx] = have
+    return have
+
+
+def release_record_buffers() -> None:
+    for d_out, d_cnt, _ in _RECORD_BUFFERS.values():
+        d_out.free()
+        d_cnt.free()
+    _RECORD_BUFFERS.clear()
 
 
 def shard_frames(raw_offsets: np.ndarray, world: int) -> int:

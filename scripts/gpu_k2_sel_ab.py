@@ -51,4 +51,12 @@ for rnd in range(2):
             assert int(d_cnt.to_array(np.uint64, 1)[0]) == 781
             line += f" | 1M v{v} {ms1:6.2f}"
         print(line, flush=True)
+for sel in (2, 0):
+    L.check(lib.hvd_debug_set(b"mfma_force_sel", sel))
+    for vv in (18, 17, 19, 15, 12, 9, 18):
+        L.check(lib.hvd_debug_set(b"vmatch_variant", vv))
+        recs, ms, sd = timed(lambda: lib5.match_videos())
+        assert np.array_equal(recs, recs0)
+        print(f"sel {sel} vmatch_variant {vv}: cfg5 search {ms:7.2f} +- {sd:4.2f} ms", flush=True)
+L.check(lib.hvd_debug_set(b"vmatch_variant", 0))
 L.check(lib.hvd_debug_set(b"mfma_force_sel", -1))
