@@ -50,18 +50,20 @@ for seed in range(first, first + nseeds):
     cap = max(len(want) + 10, 16)
     d_pairs = L.DeviceBuffer(16 * cap); d_cnt = L.DeviceBuffer(8); d_cnt.zero()
     tg = time.time()
+    sel = int(rng.choice([-1, -1, 0, 1, 2, 2]))  # round 5: which 128 bits the first stage sees -- the probe's choice or forced
+    L.check(lib.hvd_debug_set(b"mfma_force_sel", sel))
     M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n, d_grp.ptr if d_grp else None, md, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, variant)
     cnt = int(d_cnt.to_array(np.uint64, 1)[0])
     tg = time.time() - tg
     t_gpu += tg
     if tg > slow[0]:
-        slow = (tg, f"seed {seed} n={n} kind={kind} md={md} variant={variant} pairs={cnt}")
+        slow = (tg, f"seed {seed} n={n} kind={kind} md={md} variant={variant} sel={sel} pairs={cnt}")
     got = d_pairs.to_array(L.PAIR_DTYPE, min(cnt, cap))
     got = got[np.lexsort((got["j"], got["i"]))]
     ok = cnt == len(want) and np.array_equal(got, want)
     if not ok:
         bad += 1
-        print(f"MISMATCH seed {seed}: n={n} kind={kind} md={md} variant={variant} group={group is not None} got {cnt} want {len(want)}", flush=True)
+        print(f"MISMATCH seed {seed}: n={n} kind={kind} md={md} variant={variant} sel={sel} group={group is not None} got {cnt} want {len(want)}", flush=True)
     for b in (d_db, d_img, d_pairs, d_cnt, d_grp):
         if b is not None:
             b.free()

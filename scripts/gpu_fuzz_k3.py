@@ -45,6 +45,7 @@ for seed in range(first, first + nseeds):
         fr[off[b]:off[b] + k] = synth.flip_bits(fr[off[a]:off[a] + k], np.clip(rng.integers(md - 3, md + 4, k), 0, 255), rng)
     tol = int(rng.choice([31, 31, 31, 0, 20, 63]))
     want = O.match_videos(fr, off, tol)
+    L.check(lib.hvd_debug_set(b"mfma_force_sel", int(rng.choice([-1, 0, 1, 2]))))  # round 5: the first stage's 128 bits
     res = {}
     for v in FORMS:
         L.check(lib.hvd_debug_set(b"vmatch_variant", v))
@@ -72,5 +73,6 @@ for seed in range(first, first + nseeds):
                 bad += 1
                 print(f"CROSS MISMATCH seed {seed}: V={V} n={n} kind={kind} tol={tol} form={v}: got {len(got)} want {len(exp)}", flush=True)
     L.check(lib.hvd_debug_set(b"vmatch_variant", 0))
+    L.check(lib.hvd_debug_set(b"mfma_force_sel", -1))
 print(f"{nseeds} seeds from {first}: {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

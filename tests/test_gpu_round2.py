@@ -412,7 +412,9 @@ def test_k2_auto_variant_picks_the_form_from_the_data(gpu, hvd, oracle):
     assert np.array_equal(hvd.allpairs_hamming(st2, 31), want2)
     form, surv = _auto_form(gpu)
     gpu.check(gpu.load().hvd_debug_get(b"mfma_auto_half", C.byref(half)))
-    assert form == 12 and half.value == 0 and surv > 1000, (form, surv, half.value)
+    # (round 5: the probe's third selection, bits 0..63 + 192..255, needs BOTH prototypes to agree -- 1/4096 of the pairs instead
+    # of 1/64 -- and is what it picks; still far too many survivors for anything but the register form)
+    assert form == 12 and half.value == 2 and surv > 1000, (form, surv, half.value)
     # every explicit form agrees on the structured DB too (the fetch forms go through their survivor path all the time)
     from test_gpu_parity import _run_variant
 
