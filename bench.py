@@ -674,7 +674,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             per_rank5 = [json.loads(p_) for p_ in rdzv.allgather(json.dumps({"rank": rank, "last_pass": mine5}).encode())]
             # the search's kernel walks every tile of the upper triangle of kept x kept frames (pairs inside one video are
             # computed and then dropped): 2 MFMAs of 2*32*32*64 flop per 1024 comparisons in the first stage; the forms that
-            # settle survivors on the matrix pipe execute more (PMC: profiles/r04_pmc_k2_*), the pair-queue form does not
+            # settle survivors on the matrix pipe execute more (PMC: profiles/r04_pmc_k2_*, r05_pmc_cfg5.txt), the pair-queue form does not
             exec_cmp5 = float(kept5) * (float(kept5) - 1.0) / 2.0 / world
             flop5 = exec_cmp5 / 1024.0 * 2.0 * 131072.0
             search5 = {"ms": round(search5_ms, 3), "ms_sd": round(search5_sd, 3), "form": int(fv5.value),
@@ -688,7 +688,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                                     "frac": round(flop5 / (search5_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS, 4),
                                     "flop_per_launch": flop5,
                                     "basis": "first-stage MFMAs only (2 per 1024 executed comparisons, per rank) over the time of the "
-                                             "whole call; counters: profiles/r04_pmc_k2_structured18.txt, profiles/r04_pmc_cfg5.txt",
+                                             "whole call; counters: profiles/r05_pmc_cfg5.txt (r04_pmc_k2_structured18.txt: stall breakdown)",
                                     "traffic": load_traffic(f"config5_search_v{V}x{F}_w{world}"),
                                     "traffic_source": TRAFFIC_SOURCE}}
             extras["cfg5"] = {"workload": f"BASELINE configs[4]: {V} synthetic videos x {F} distinct 64x64 frames generated in HBM -> PDQ hash -> "

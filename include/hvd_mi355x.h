@@ -246,7 +246,7 @@ int hvd_dev_pdq_hash_frames(const void* d_frames, int64_t n, int h, int w, int c
 int hvd_dev_allpairs_hamming256(const void* d_db, int64_t n, const void* d_group, int max_dist, int rank, int world,
                                 void* d_pairs, int64_t cap, void* d_count, int variant);
 
-/* Matrix-core form of the same pass (variants 8..11): the DB is first
+/* Matrix-core form of the same pass (variants 8..19): the DB is first
  * rewritten as its FP4 image (every bit b as the e2m1 number 1-2b; 128 bytes per hash,
  * rows padded to a multiple of 1024), then v_mfma_f32_32x32x64_f8f6f4 produces
  * 256 - 2*hamming for 32x32 pairs at a time. Output contract identical to

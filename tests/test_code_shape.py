@@ -5,7 +5,7 @@ presence of the instructions the design is built on. The all-pairs kernel's own 
 A compiler bump or a two-register change would cost 25 % silently; only a bench run would show it.
 
 hipcc cross-compiles the two kernel files for gfx950 with --cuda-device-only -S (no GPU needed, ~10 s) and this module
-reads every kernel's `.amdhsa` metadata and ISA text. Budget table: DESIGN.md section 4 ("Code shape").
+reads every kernel's `.amdhsa` metadata and ISA text. Budget table: DESIGN.md section 4.5 ("Code shape").
 """
 import os
 import re
