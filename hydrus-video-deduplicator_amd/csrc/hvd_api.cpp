@@ -83,6 +83,8 @@ struct Ctx {
     // pinned, device-visible staging of the small-operand path of hvd_match_two: operands, then the two counters
     uint8_t* m_pin = nullptr;
     int32_t m_seq = 0;
+    hipStream_t m_srv_stream = nullptr;  // the match server's own stream (k_match_server stays resident between calls)
+    int32_t m_launch = 0;                // id of the last server launch; hdr[7] == m_launch: that server has left
     std::mutex m_mu;
     // grow-only device scratch of the host-buffer entry points and of the video-level reduction: nothing is
     // allocated or freed per call once the sizes have been seen (h_mu serialises the users)
@@ -103,6 +105,8 @@ constexpr int kMaxCtx = 16;
 Ctx g_ctx[kMaxCtx];
 int g_nctx = 0;                 // contexts of the group (0 before hvd_init / hvd_init_devices)
 bool g_group_rccl = false;      // the group's contexts hold communicators of one ncclCommInitAll
+int g_match_server = 1;         // hvd_debug_set "match_server": hvd_match_two's small operands go to a resident workgroup (1) or to one launch per call (0)
+constexpr unsigned long long kMatchServerIdleUs = 300;  // the server leaves after this long without a call
 thread_local int t_ctx = 0;     // the calling thread's current context
 #define g (g_ctx[t_ctx])
 std::mutex g_mu;
@@ -312,6 +316,10 @@ void shutdown_context(int idx) {
             if (*p) (void)hipFree(*p);
         for (void* p : g.scr)
             if (p) (void)hipFree(p);
+        if (g.m_srv_stream) {  // (a resident match server leaves by itself within its idle limit)
+            (void)hipStreamSynchronize(g.m_srv_stream);
+            (void)hipStreamDestroy(g.m_srv_stream);
+        }
         if (g.m_pin) (void)hipHostFree(g.m_pin);
         g.~Ctx();
         new (&g) Ctx();
@@ -753,6 +761,10 @@ int hvd_debug_set(const char* key, int value) {
     }
     if (strcmp(key, "pdq_fused_down512") == 0) {
         hvd::g_pdq_fused_down512 = value != 0;
+        return HVD_OK;
+    }
+    if (strcmp(key, "match_server") == 0) {  // hvd_match_two, small operands: 1 resident match server (default), 0 one launch per call
+        g_match_server = value != 0;
         return HVD_OK;
     }
     if (strcmp(key, "copy_nt") == 0) {  // hvd_hasher_push: non-temporal stores into the pinned ring (1, default where the CPU has them) or plain memcpy (0)
@@ -1296,7 +1308,7 @@ int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, in
         // operands fit in LDS: the kernel reads them from pinned host memory and writes the counters there, then a
         // sequence word the host polls (a stream synchronisation costs more than the whole kernel)
         if (!g.m_pin) {
-            HIP_TRY(hipHostMalloc((void**)&g.m_pin, small + 64, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void**)&g.m_pin, small + 64, hipHostMallocCoherent));  // (fine-grained: a RUNNING kernel sees the host's stores)
             memset(g.m_pin + small, 0, 64);
         }
         uint8_t* pb = g.m_pin + 32 * (size_t)na;
@@ -1304,6 +1316,46 @@ int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, in
         memcpy(g.m_pin, a, 32 * (size_t)na);
         memcpy(pb, b, 32 * (size_t)nb);
         const int32_t seq = ++g.m_seq == 0 ? ++g.m_seq : g.m_seq;
+        if (g_match_server) {
+            // Round 5: post the request to the resident match server (k_match_server) and poll for the answer -- no launch and
+            // no synchronisation per call while calls come back to back (the VP-tree's pattern); the server is (re)started
+            // when it has left (idle for kMatchServerIdleUs) or has never run.
+            auto start_server = [&]() -> int {
+                if (!g.m_srv_stream) HIP_TRY(hipStreamCreateWithFlags(&g.m_srv_stream, hipStreamNonBlocking));
+                g.m_launch = g.m_launch == 0x7FFFFFFF ? 1 : g.m_launch + 1;
+                HIP_TRY(hvd::launch_match_server((const uint32_t*)g.m_pin, (int32_t*)(g.m_pin + small), seq - 1,
+                                                 g.m_launch, 100ull * kMatchServerIdleUs, g.m_srv_stream));
+                return HVD_OK;
+            };
+            ph[4] = (int32_t)na;
+            ph[5] = (int32_t)nb;
+            ph[6] = max_dist;
+            __atomic_store_n(&ph[3], seq, __ATOMIC_RELEASE);
+            if (g.m_launch == 0 || __atomic_load_n(&ph[7], __ATOMIC_ACQUIRE) == g.m_launch)
+                if (int rc = start_server()) return rc;
+            bool seen = false;
+            for (int attempt = 0; attempt < 3 && !seen; ++attempt) {
+                for (long spin = 0; spin < 40000000; ++spin) {
+                    if (__atomic_load_n(&ph[2], __ATOMIC_ACQUIRE) == seq) {
+                        seen = true;
+                        break;
+                    }
+                    // the server may have left between our look at hdr[7] and its last poll: start another, it finds the request
+                    if ((spin & 1023) == 1023 && __atomic_load_n(&ph[7], __ATOMIC_ACQUIRE) == g.m_launch) break;
+                }
+                if (!seen) {
+                    if (__atomic_load_n(&ph[7], __ATOMIC_ACQUIRE) != g.m_launch) break;  // still running and silent: give up below
+                    if (int rc = start_server()) return rc;
+                }
+            }
+            if (!seen) {
+                HIP_TRY(hipStreamSynchronize(g.m_srv_stream));
+                if (__atomic_load_n(&ph[2], __ATOMIC_ACQUIRE) != seq) return fail(HVD_ERR_HIP, "match server did not answer");
+            }
+            *q_hits = ph[0];
+            *t_hits = ph[1];
+            return HVD_OK;
+        }
         HIP_TRY(hvd::launch_match_two_small((const uint32_t*)g.m_pin, (uint32_t)na, (const uint32_t*)pb, (uint32_t)nb,
                                             (uint32_t)max_dist, (int32_t*)(g.m_pin + small), seq, g.stream));
         bool seen = false;

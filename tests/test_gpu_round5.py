@@ -320,3 +320,56 @@ def test_k2_probe_picks_the_mixed_selection_when_the_middle_bits_are_degenerate(
         _pairs_equal(got, oracle.allpairs(db, 31, num_threads=8, cap=1 << 22), "auto variant on the mixed selection")
     finally:
         d_db.free()
+
+
+# ------------------------------------------------------------------ the resident match server behind matchHashBytes ----------
+
+def test_match_server_answers_like_the_per_call_kernel_and_the_oracle(gpu, hvd, oracle):
+    """hvd_match_two's small operands are served by a workgroup that stays resident between calls (round 5): back to back
+    (server alive), after pauses longer than its idle limit (server restarted), from two threads, with the server switched
+    off -- always the oracle's counters (vpdqpy/vpdqpy.py:49-56, db/vptree.py:29-31 call shape)."""
+    import threading
+    import time
+
+    lib = gpu.load()
+    fr, off, _ = hvd.synth.video_hashes(60, seed=95, frames_per_video=(0, 70), copy_fraction=0.5)
+    blobs = [fr[off[v]:off[v + 1]].tobytes() for v in range(60)]
+    pairs = [(a, b) for a in range(0, 60, 3) for b in range(60)]
+    want = {(a, b): oracle.match_two(blobs[a], blobs[b], 31) for a, b in pairs}
+    assert sum(1 for v in want.values() if v != (0, 0)) > 20
+
+    def sweep(pause_every=0):
+        for k, (a, b) in enumerate(pairs):
+            if pause_every and k % pause_every == 0:
+                time.sleep(0.003)  # ten idle limits: the server has left and is started again by the next call
+            assert hvd.vpdq.match_counts(blobs[a], blobs[b], 31) == want[(a, b)], (a, b)
+
+    try:
+        for mode in (1, 0, 1):
+            gpu.check(lib.hvd_debug_set(b"match_server", mode))
+            sweep()
+            sweep(pause_every=97)
+        errs = []
+
+        def worker():
+            try:
+                sweep(pause_every=211)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=worker) for _ in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        # tolerances other than 31, empty operands, one frame, and the distance the reference derives from the answer
+        for tol in (0, 10, 64, 255):
+            for a, b in pairs[:40]:
+                assert hvd.vpdq.match_counts(blobs[a], blobs[b], tol) == oracle.match_two(blobs[a], blobs[b], tol)
+        assert hvd.vpdq.match_counts(b"", blobs[3], 31) == (0, 0)
+        d = hvd.calculate_distance(blobs[3], blobs[3])
+        assert d == (1 if len(blobs[3]) else 101)
+        gpu.check(lib.hvd_device_synchronize())  # returns: the server leaves by itself
+    finally:
+        gpu.check(lib.hvd_debug_set(b"match_server", 1))
