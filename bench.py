@@ -1081,7 +1081,8 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                     "one call per pair from Python (the reference's VP-tree call pattern)",
             "us_per_call": round(per_call * 1e6, 1), "calls": ncall,
             "frame_comparisons_per_s": sig(4096 / per_call, 3),
-            "note": "launch-bound by construction; the batch entry points above replace the loop, not the callee"}
+            "note": "latency-bound by construction (round 5: served by a resident workgroup that polls pinned host memory, no launch "
+                    "per call); the batch entry points above replace the loop, not the callee"}
 
         # the unchanged pipeline's search loop (dedup.py:468-491) against the VpTreeManager-compatible facade: one cached GPU
         # pass, then one lookup + SQL fan-out per file

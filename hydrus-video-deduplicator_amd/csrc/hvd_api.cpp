@@ -776,6 +776,11 @@ int hvd_debug_set(const char* key, int value) {
 
 int hvd_debug_get(const char* key, int* out_value) {
     if (!key || !out_value) return fail(HVD_ERR_ARG, "NULL argument");
+    if (strcmp(key, "match_server_ticks") == 0) {  // -DHVD_MATCH_SERVER_TIMING builds: 10 ns ticks the server spent on the last request
+        const size_t small = hvd::match_two_small_limit();
+        *out_value = g.m_pin ? reinterpret_cast<volatile int32_t*>(g.m_pin + small)[8] : 0;
+        return HVD_OK;
+    }
     if (strcmp(key, "copy_nt") == 0) {  // (host only: no device needed)
         *out_value = hvd::stream_copy_nt_level();
         return HVD_OK;
@@ -1320,37 +1325,38 @@ int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, in
             // Round 5: post the request to the resident match server (k_match_server) and poll for the answer -- no launch and
             // no synchronisation per call while calls come back to back (the VP-tree's pattern); the server is (re)started
             // when it has left (idle for kMatchServerIdleUs) or has never run.
+            const uint32_t seq21 = (uint32_t)seq & 0x1FFFFFu;
             auto start_server = [&]() -> int {
                 if (!g.m_srv_stream) HIP_TRY(hipStreamCreateWithFlags(&g.m_srv_stream, hipStreamNonBlocking));
                 g.m_launch = g.m_launch == 0x7FFFFFFF ? 1 : g.m_launch + 1;
-                HIP_TRY(hvd::launch_match_server((const uint32_t*)g.m_pin, (int32_t*)(g.m_pin + small), seq - 1,
+                HIP_TRY(hvd::launch_match_server((const uint32_t*)g.m_pin, (int32_t*)(g.m_pin + small), (seq21 - 1u) & 0x1FFFFFu,
                                                  g.m_launch, 100ull * kMatchServerIdleUs, g.m_srv_stream));
                 return HVD_OK;
             };
-            ph[4] = (int32_t)na;
-            ph[5] = (int32_t)nb;
-            ph[6] = max_dist;
-            __atomic_store_n(&ph[3], seq, __ATOMIC_RELEASE);
-            if (g.m_launch == 0 || __atomic_load_n(&ph[7], __ATOMIC_ACQUIRE) == g.m_launch)
+            // ONE 64-bit word carries the whole request: a poll that sees the new sequence number has everything
+            const unsigned long long word = ((unsigned long long)seq21 << 43) | ((unsigned long long)(uint32_t)max_dist << 32) |
+                                            ((unsigned long long)(uint32_t)na << 16) | (unsigned long long)(uint32_t)nb;
+            __atomic_store_n(reinterpret_cast<volatile unsigned long long*>(ph + 4), word, __ATOMIC_RELEASE);
+            if (g.m_launch == 0 || __atomic_load_n(&ph[3], __ATOMIC_ACQUIRE) == g.m_launch)
                 if (int rc = start_server()) return rc;
             bool seen = false;
             for (int attempt = 0; attempt < 3 && !seen; ++attempt) {
                 for (long spin = 0; spin < 40000000; ++spin) {
-                    if (__atomic_load_n(&ph[2], __ATOMIC_ACQUIRE) == seq) {
+                    if ((uint32_t)__atomic_load_n(&ph[2], __ATOMIC_ACQUIRE) == seq21) {
                         seen = true;
                         break;
                     }
-                    // the server may have left between our look at hdr[7] and its last poll: start another, it finds the request
-                    if ((spin & 1023) == 1023 && __atomic_load_n(&ph[7], __ATOMIC_ACQUIRE) == g.m_launch) break;
+                    // the server may have left between our look at hdr[3] and its last poll: start another, it finds the request
+                    if ((spin & 1023) == 1023 && __atomic_load_n(&ph[3], __ATOMIC_ACQUIRE) == g.m_launch) break;
                 }
                 if (!seen) {
-                    if (__atomic_load_n(&ph[7], __ATOMIC_ACQUIRE) != g.m_launch) break;  // still running and silent: give up below
+                    if (__atomic_load_n(&ph[3], __ATOMIC_ACQUIRE) != g.m_launch) break;  // still running and silent: give up below
                     if (int rc = start_server()) return rc;
                 }
             }
             if (!seen) {
                 HIP_TRY(hipStreamSynchronize(g.m_srv_stream));
-                if (__atomic_load_n(&ph[2], __ATOMIC_ACQUIRE) != seq) return fail(HVD_ERR_HIP, "match server did not answer");
+                if ((uint32_t)__atomic_load_n(&ph[2], __ATOMIC_ACQUIRE) != seq21) return fail(HVD_ERR_HIP, "match server did not answer");
             }
             *q_hits = ph[0];
             *t_hits = ph[1];

@@ -231,8 +231,34 @@ __device__ __forceinline__ void match_two_small_body(uint32_t* sm, const uint32_
         s_qt[0] = 0;
         s_qt[1] = 0;
     }
-    for (uint32_t k = threadIdx.x; k < na * 8u; k += blockDim.x) sa[(k >> 3) * 9u + (k & 7u)] = a[k];
-    for (uint32_t k = threadIdx.x; k < nb * 8u; k += blockDim.x) sb[(k >> 3) * 9u + (k & 7u)] = b[k];
+    // Both operands sit in pinned HOST memory: every load is a PCIe round trip (~2 us). All of a lane's loads -- 16 bytes each,
+    // up to kB per operand and trip -- are issued before the first is waited for (round 5: the dword-by-dword loops paid the
+    // round trip once per iteration, 8 of the server's 15 us per call).
+    constexpr uint32_t kB = 3;
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint4* b4 = reinterpret_cast<const uint4*>(b);
+    const uint32_t na2 = na * 2u, nb2 = nb * 2u;
+    for (uint32_t k0 = 0; k0 < max(na2, nb2); k0 += kB * blockDim.x) {
+        uint4 va[kB], vb[kB];
+#pragma unroll
+        for (uint32_t u = 0; u < kB; ++u) {
+            const uint32_t k = k0 + u * blockDim.x + threadIdx.x;
+            va[u] = k < na2 ? a4[k] : make_uint4(0u, 0u, 0u, 0u);
+            vb[u] = k < nb2 ? b4[k] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kB; ++u) {
+            const uint32_t k = k0 + u * blockDim.x + threadIdx.x;
+            if (k < na2) {
+                uint32_t* d = sa + (k >> 1) * 9u + (k & 1u) * 4u;
+                d[0] = va[u].x; d[1] = va[u].y; d[2] = va[u].z; d[3] = va[u].w;
+            }
+            if (k < nb2) {
+                uint32_t* d = sb + (k >> 1) * 9u + (k & 1u) * 4u;
+                d[0] = vb[u].x; d[1] = vb[u].y; d[2] = vb[u].z; d[3] = vb[u].w;
+            }
+        }
+    }
     for (uint32_t j = threadIdx.x; j < na + nb; j += blockDim.x) qf[j] = 0u;
     __syncthreads();
     // every (query frame, target frame) pair is one work item: all 256 lanes are busy for any na, nb
@@ -281,53 +307,58 @@ __global__ __launch_bounds__(256) void k_match_two_small(const uint32_t* __restr
 // memory, reads the operands the host has copied next to it, compares out of LDS and writes the counters and the request's
 // sequence number back; the host posts and polls -- no launch, no stream synchronisation per call. The workgroup leaves by
 // itself after `idle_ticks` of the 100 MHz wall clock without a request (and after `max_polls` polls whatever the clock says),
-// announcing it in hdr[7], so that a device-wide synchronisation waits a few hundred microseconds at most; the host starts
-// it again with the next call. hdr: [0] q_hits, [1] t_hits, [2] sequence number answered, [3] sequence number requested,
-// [4] na, [5] nb, [6] max_dist, [7] id of the server launch that has exited.
-__global__ __launch_bounds__(256) void k_match_server(const uint32_t* __restrict__ ops, int32_t* hdr, int32_t last,
-                                                      int32_t launch_id, unsigned long long idle_ticks, uint32_t max_polls) {
+// announcing it in hdr[3], so that a device-wide synchronisation waits a few hundred microseconds at most; the host starts
+// it again with the next call. hdr (int32 words): [0] q_hits, [1] t_hits, [2] sequence number answered (21 bits), [3] id of the
+// server launch that has exited, [4..5] the 64-bit request word (below).
+constexpr uint32_t kServerLanes = 1024;  // 16 waves: the operands' loads and the na x nb compares spread over four times the lanes
+// request word (ONE 64-bit load per poll brings everything): seq (21 bits) << 43 | max_dist (9) << 32 | na (16) << 16 | nb (16)
+__global__ __launch_bounds__(kServerLanes) void k_match_server(const uint32_t* __restrict__ ops, int32_t* hdr, uint32_t last,
+                                                               int32_t launch_id, unsigned long long idle_ticks, uint32_t max_polls) {
     extern __shared__ uint32_t sm[];
     __shared__ uint32_t s_qt[2];
-    __shared__ int32_t s_req[4];
+    __shared__ unsigned long long s_req;
+    unsigned long long* req = reinterpret_cast<unsigned long long*>(hdr + 4);
     unsigned long long t_idle = wall_clock64();
     for (;;) {
         if (threadIdx.x == 0) {
-            int32_t r = last;
+            unsigned long long w = 0;
+            bool got = false;
             for (uint32_t polls = 0; polls < max_polls; ++polls) {
-                r = __hip_atomic_load(&hdr[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (r != last || wall_clock64() - t_idle > idle_ticks) break;
+                w = __hip_atomic_load(req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                got = (uint32_t)(w >> 43) != last;
+                if (got || wall_clock64() - t_idle > idle_ticks) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            s_req[0] = r;
-            if (r != last) {
-                s_req[1] = __hip_atomic_load(&hdr[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                s_req[2] = __hip_atomic_load(&hdr[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                s_req[3] = __hip_atomic_load(&hdr[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            s_req = got ? w : ~0ull;
         }
         __syncthreads();
-        const int32_t r = s_req[0];
-        if (r == last) break;  // nothing came: leave
-        const uint32_t na = (uint32_t)s_req[1], nb = (uint32_t)s_req[2], md = (uint32_t)s_req[3];
+        const unsigned long long w = s_req;
+        const unsigned long long t_seen = wall_clock64();
+        if (w == ~0ull) break;  // nothing came: leave
+        const uint32_t seq = (uint32_t)(w >> 43), md = (uint32_t)(w >> 32) & 511u, na = (uint32_t)(w >> 16) & 0xFFFFu, nb = (uint32_t)w & 0xFFFFu;
         // the operands were rewritten by the host since this workgroup last read them: nothing of them may come out of
         // this CU's vector cache (an acquire at system scope invalidates it)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         int32_t q = 0, t = 0;
-        if (40ull * ((unsigned long long)na + nb) <= kMatchSmallBytes)  // (the host never posts more; a corrupt header must not run off LDS)
+        if (40ull * ((unsigned long long)na + nb) <= kMatchSmallBytes)  // (the host never posts more; a corrupt word must not run off LDS)
             match_two_small_body(sm, ops, na, ops + 8u * (size_t)na, nb, md, s_qt, &q, &t);
         if (threadIdx.x == 0) {
             hdr[0] = q;
             hdr[1] = t;
+#ifdef HVD_MATCH_SERVER_TIMING
+            hdr[8] = (int32_t)(wall_clock64() - t_seen);
+#endif
             __threadfence_system();
-            __hip_atomic_store(&hdr[2], r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&hdr[2], (int32_t)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        last = r;
+        (void)t_seen;
+        last = seq;
         t_idle = wall_clock64();
         __syncthreads();  // (s_req and s_qt are rewritten by the next round)
     }
     if (threadIdx.x == 0) {
         __threadfence_system();
-        __hip_atomic_store(&hdr[7], launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&hdr[3], launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -407,7 +438,7 @@ hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_
 uint32_t match_two_small_limit() { return kMatchSmallBytes; }
 
 // one resident workgroup serving hvd_match_two calls out of pinned host memory (k_match_server, above)
-hipError_t launch_match_server(const uint32_t* ops, int32_t* hdr, int32_t last, int32_t launch_id, unsigned long long idle_ticks,
+hipError_t launch_match_server(const uint32_t* ops, int32_t* hdr, uint32_t last, int32_t launch_id, unsigned long long idle_ticks,
                                hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = kMatchSmallBytes;  // 40 B per frame hash of both operands at most
@@ -416,7 +447,7 @@ hipError_t launch_match_server(const uint32_t* ops, int32_t* hdr, int32_t last, 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_match_server, dim3(1), dim3(256), lds, s, ops, hdr, last, launch_id, idle_ticks, 4000000u);
+    hipLaunchKernelGGL(k_match_server, dim3(1), dim3(kServerLanes), lds, s, ops, hdr, last, launch_id, idle_ticks, 4000000u);
     return hipGetLastError();
 }
 

@@ -23,3 +23,13 @@ for mode in (1, 0, 1, 0):
     for _ in range(4000):
         lib.hvd_match_two(blobs[0], 64, blobs[1], 64, 31, C.byref(q), C.byref(t_))
     print(f"match_server {mode} raw hvd_match_two       : {(time.perf_counter() - t) / 4000 * 1e6:6.2f} us per call")
+if os.environ.get("HVD_LIB_PATH"):
+    # timing build (-DHVD_MATCH_SERVER_TIMING): hdr[8] = 10 ns ticks from "request seen" to "answer ready" inside the server
+    L.check(lib.hvd_debug_set(b"match_server", 1))
+    q, t_ = C.c_int32(0), C.c_int32(0)
+    import ctypes
+    tk = []
+    for _ in range(2000):
+        lib.hvd_match_two(blobs[0], 64, blobs[1], 64, 31, C.byref(q), C.byref(t_))
+        v = C.c_int(0); lib.hvd_debug_get(b"match_server_ticks", C.byref(v)); tk.append(v.value)
+    print("in-kernel us (seen -> answer ready): median", np.median(tk) / 100.0, "min", min(tk) / 100.0)
