@@ -334,24 +334,34 @@ class VpTreeManager:
     # schema, nothing is written to the user's file, and a ROLLBACK takes them back together with the rows they describe.
     # Commits by OTHER connections do not fire them; SQLite's data_version (O(1), read at every look) reports those, and
     # the two numbers are then taken from the table again.
-    _ROW_SUM = "{0}.phash_id * 1000003 + {0}.hash_id"
+    # Round 5: the checksum was the plain sum of phash_id * 1000003 + hash_id -- linear, so two files swapping
+    # their phashes left it unchanged, and SUM() overflowed SQLite's integers around 4 M phash ids (every search on such a
+    # database failed). Now a row's term is a PRODUCT of two bounded residues (< 2^47: a swap changes the sum), the state is
+    # kept modulo 2^61 everywhere (triggers and resync agree), and a change counter v rides along: (v, c, s).
+    _M = 2305843009213693952  # 2^61
+    _ROW_TERM = "((({0}.phash_id * 1000003) % 2147483647) * ({0}.hash_id % 65521 + 1))"
     _VERSION_SQL = (
-        "CREATE TEMP TABLE IF NOT EXISTS hvd_amd_map_state ( c INTEGER, s INTEGER )",
+        "CREATE TEMP TABLE IF NOT EXISTS hvd_amd_map_state ( v INTEGER, c INTEGER, s INTEGER )",
         "CREATE TEMP TRIGGER IF NOT EXISTS hvd_amd_map_ins AFTER INSERT ON main.shape_perceptual_hash_map "
-        "BEGIN UPDATE hvd_amd_map_state SET c = c + 1, s = s + " + _ROW_SUM.format("NEW") + "; END",
+        "BEGIN UPDATE hvd_amd_map_state SET v = v + 1, c = c + 1, s = (s + " + _ROW_TERM.format("NEW") + f") % {_M}; END",
         "CREATE TEMP TRIGGER IF NOT EXISTS hvd_amd_map_del AFTER DELETE ON main.shape_perceptual_hash_map "
-        "BEGIN UPDATE hvd_amd_map_state SET c = c - 1, s = s - (" + _ROW_SUM.format("OLD") + "); END",
+        "BEGIN UPDATE hvd_amd_map_state SET v = v + 1, c = c - 1, s = (s + " + f"{_M} - " + _ROW_TERM.format("OLD") + f") % {_M}; END",
         "CREATE TEMP TRIGGER IF NOT EXISTS hvd_amd_map_upd AFTER UPDATE ON main.shape_perceptual_hash_map "
-        "BEGIN UPDATE hvd_amd_map_state SET s = s - (" + _ROW_SUM.format("OLD") + ") + " + _ROW_SUM.format("NEW") + "; END",
+        "BEGIN UPDATE hvd_amd_map_state SET v = v + 1, s = (s + " + f"{_M} - " + _ROW_TERM.format("OLD") + " + " + _ROW_TERM.format("NEW")
+        + f") % {_M}; END",
     )
+    # (the sum over the table in two halves of a term, 24 low bits and the rest, so that no partial sum can overflow 2^63 for
+    # any table SQLite can hold; (hi << 24) mod 2^61 = (hi mod 2^37) << 24)
     _RESYNC_SQL = (
         "DELETE FROM temp.hvd_amd_map_state",
-        "INSERT INTO temp.hvd_amd_map_state SELECT COUNT(*), COALESCE(SUM(" + _ROW_SUM.format("m") + "), 0) "
+        "INSERT INTO temp.hvd_amd_map_state SELECT 0, COUNT(*), "
+        "( COALESCE(SUM(" + _ROW_TERM.format("m") + " & 16777215), 0) % " + f"{_M}"
+        " + ( ( COALESCE(SUM(" + _ROW_TERM.format("m") + " >> 24), 0) % 137438953472 ) << 24 ) ) % " + f"{_M} "
         "FROM main.shape_perceptual_hash_map AS m",
     )
 
     def _map_state(self, resync: bool):
-        """(row count, row checksum) of shape_perceptual_hash_map from the trigger-kept state, or None where the triggers
+        """(change counter, row count, row checksum) of shape_perceptual_hash_map from the trigger-kept state, or None where the triggers
         cannot be created (a read-only connection: nothing can change through it, data_version alone decides)."""
         if self._map_triggers is None:
             try:
@@ -366,7 +376,7 @@ class VpTreeManager:
         if resync or self.db.execute("SELECT COUNT(*) FROM temp.hvd_amd_map_state").fetchone()[0] != 1:
             for stmt in self._RESYNC_SQL:
                 self.db.execute(stmt)
-        return tuple(self.db.execute("SELECT c, s FROM temp.hvd_amd_map_state").fetchone())
+        return tuple(self.db.execute("SELECT v, c, s FROM temp.hvd_amd_map_state").fetchone())
 
     def _map_fresh(self) -> None:
         """Make the in-memory copy of shape_perceptual_hash_map current. data_version is read at EVERY look (another

@@ -544,3 +544,37 @@ def test_phash_map_cache_survives_rollbacks_and_foreign_commits(hvd, oracle, tmp
     other.close()
     assert set(tree.search_file(1, 0)) == {(1, 0), (2, 0)}
     assert set(tree.search_file(1, 0)) == {(1, 0), (2, 0)}
+
+
+def test_phash_map_token_sees_a_swap_and_survives_large_ids(hvd, oracle):
+    """the cached copy of shape_perceptual_hash_map was keyed on a LINEAR row checksum -- two files that swap
+    their perceptual hashes (the reference's DELETE + INSERT re-hash path) left count and sum unchanged -- and its SUM()
+    overflowed SQLite's integers around 4 M phash ids, after which every search on the database failed."""
+    import sqlite3
+
+    rng = np.random.default_rng(12)
+    conn = sqlite3.connect(":memory:")
+    for stmt in SCHEMA:
+        conn.execute(stmt)
+    b1 = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
+    b2 = rng.integers(0, 256, 64, dtype=np.uint8).tobytes()
+    big = 4_000_000_000  # ids this large made SUM(phash_id * 1000003 + hash_id) overflow with a few rows
+    conn.execute("INSERT INTO shape_perceptual_hashes VALUES (?, ?)", (big + 1, b1))
+    conn.execute("INSERT INTO shape_perceptual_hashes VALUES (?, ?)", (big + 2, b2))
+    for h in range(1, 5):
+        conn.execute("INSERT INTO files VALUES (?, ?)", (big + 10 + h, f"{h:064x}"))
+    conn.executemany("INSERT INTO shape_perceptual_hash_map VALUES (?, ?)",
+                     [(big + 1, big + 11), (big + 2, big + 12), (big + 1, big + 13), (big + 2, big + 14)])
+    conn.commit()
+    tree = hvd.vptree.VpTreeManager(conn, matcher=OracleMatcher(oracle))
+    assert set(tree.search_file(big + 11, 0)) == {(big + 11, 0), (big + 13, 0)}
+    # files 11 and 12 swap their phashes: (p1,11),(p2,12) -> (p2,11),(p1,12): same row count, same LINEAR sum
+    conn.execute("DELETE FROM shape_perceptual_hash_map WHERE hash_id IN (?, ?)", (big + 11, big + 12))
+    conn.executemany("INSERT INTO shape_perceptual_hash_map VALUES (?, ?)", [(big + 2, big + 11), (big + 1, big + 12)])
+    assert set(tree.search_file(big + 11, 0)) == {(big + 11, 0), (big + 14, 0)}
+    assert set(tree.search_file(big + 12, 0)) == {(big + 12, 0), (big + 13, 0)}
+    # the trigger-kept state and a resync from the table agree (same modulus on both sides)
+    v, c, s = conn.execute("SELECT v, c, s FROM temp.hvd_amd_map_state").fetchone()
+    for stmt in hvd.vptree.VpTreeManager._RESYNC_SQL:
+        conn.execute(stmt)
+    assert conn.execute("SELECT c, s FROM temp.hvd_amd_map_state").fetchone() == (c, s) and c == 4 and 0 <= s < 2 ** 61
