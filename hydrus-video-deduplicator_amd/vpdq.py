@@ -261,8 +261,14 @@ class VideoHasher:
         if isinstance(frame, bytes):
             n, ptr, keep = len(frame), frame, frame
         else:
-            keep = np.frombuffer(frame, dtype=np.uint8)  # zero-copy view of any buffer object
-            n, ptr = keep.size, keep.ctypes.data
+            keep = None
+            if isinstance(frame, np.ndarray) and frame.flags.c_contiguous and frame.flags.writeable:
+                # (0.3 us; `.ctypes.data` builds a helper object per call: 1.1 us of the 1 us a 64x64 frame costs otherwise)
+                keep, n = frame, frame.nbytes
+                ptr = C.addressof(C.c_uint8.from_buffer(frame))
+            if keep is None:
+                keep = np.frombuffer(frame, dtype=np.uint8)  # zero-copy view of any buffer object
+                n, ptr = keep.size, keep.ctypes.data
         if n == self._frame_bytes_rgb:
             ch = 3
         elif n == self._frame_bytes_gray:
