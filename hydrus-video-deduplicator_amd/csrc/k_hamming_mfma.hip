@@ -894,12 +894,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
     const uint32_t sel = select != nullptr ? (select[3] & 3u) : sel_arg;
     const uint32_t selx0 = sel == 1u ? 4u : 0u, selx1 = sel != 0u ? 4u : 0u;
 
-    const uint32_t rb = blockIdx.x, cb = blockIdx.y;
+    // Tile (rb, cb) belongs to rank (rb + cb) mod world. Round 5: only a rank's OWN tiles are launched (grid.y = ceil(n_cb /
+    // world)): workgroup y of row block rb takes column chunk y * world + (rank - rb) mod world. Launching every tile and
+    // letting seven of eight workgroups return cost ~0.2 ns each -- 0.2 ms per form and pass at 2.8 M hashes, three forms per
+    // auto pass: 4 % of an 18 ms step at N = 8, straight out of the scaling efficiency.
+    const uint32_t rb = blockIdx.x;
+    const uint32_t cb = world > 1u ? blockIdx.y * world + (rank + world - rb % world) % world : blockIdx.y;
     const uint32_t row0 = rb * ROWS;
     const uint32_t col0 = cb * col_chunk;
+    if (col0 >= n_pad) return;  // (the last residues of a row block may lie beyond the last chunk)
     const uint32_t col1 = min(col0 + col_chunk, n_pad);
     if (!RECT && min(col1, n) <= row0 + 1u) return;  // tile entirely on/below the diagonal
-    if (world > 1u && (rb + cb) % world != rank) return;
     const uint4* __restrict__ imgq = RECT ? img_q : img;
 
     const uint32_t tid = threadIdx.x;
@@ -1464,7 +1469,8 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
         chunk = (chunk + kSuper - 1) / kSuper * kSuper;
         if ((n_pad + chunk - 1) / chunk > 65535u) chunk = round_up((n_pad + 65534u) / 65535u, kSuper);
     }
-    dim3 grid((unsigned)n_rb, (unsigned)((n_pad + chunk - 1) / chunk));
+    const uint64_t n_cb = (n_pad + chunk - 1) / chunk;
+    dim3 grid((unsigned)n_rb, (unsigned)(a.world > 1u ? (n_cb + a.world - 1) / a.world : n_cb));  // (own tiles only: see the kernel)
     uint32_t* buf = nullptr;
     hipError_t e = mfma_select_buffer(a.ctx_id, &buf);
     if (e != hipSuccess) return e;
