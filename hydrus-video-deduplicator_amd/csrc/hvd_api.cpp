@@ -106,7 +106,8 @@ Ctx g_ctx[kMaxCtx];
 int g_nctx = 0;                 // contexts of the group (0 before hvd_init / hvd_init_devices)
 bool g_group_rccl = false;      // the group's contexts hold communicators of one ncclCommInitAll
 int g_match_server = 1;         // hvd_debug_set "match_server": hvd_match_two's small operands go to a resident workgroup (1) or to one launch per call (0)
-constexpr unsigned long long kMatchServerIdleUs = 300;  // the server leaves after this long without a call
+constexpr unsigned long long kMatchServerIdleUs = 300;  // the server leaves after this long without a call ...
+constexpr unsigned long long kMatchServerLifeUs = 2000;  // ... and after this long in any case (another thread's hipFree / device-wide wait gets its turn)
 thread_local int t_ctx = 0;     // the calling thread's current context
 #define g (g_ctx[t_ctx])
 std::mutex g_mu;
@@ -1330,7 +1331,7 @@ int hvd_match_two(const uint8_t* a, int64_t na, const uint8_t* b, int64_t nb, in
                 if (!g.m_srv_stream) HIP_TRY(hipStreamCreateWithFlags(&g.m_srv_stream, hipStreamNonBlocking));
                 g.m_launch = g.m_launch == 0x7FFFFFFF ? 1 : g.m_launch + 1;
                 HIP_TRY(hvd::launch_match_server((const uint32_t*)g.m_pin, (int32_t*)(g.m_pin + small), (seq21 - 1u) & 0x1FFFFFu,
-                                                 g.m_launch, 100ull * kMatchServerIdleUs, g.m_srv_stream));
+                                                 g.m_launch, 100ull * kMatchServerIdleUs, 100ull * kMatchServerLifeUs, g.m_srv_stream));
                 return HVD_OK;
             };
             // ONE 64-bit word carries the whole request: a poll that sees the new sequence number has everything

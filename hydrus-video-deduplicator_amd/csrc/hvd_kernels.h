@@ -80,7 +80,7 @@ hipError_t launch_match_two(const uint32_t* d_a, uint32_t na, const uint32_t* d_
                             uint32_t* d_tflags, int32_t* d_hits, hipStream_t s);
 uint32_t match_two_small_limit();
 hipError_t launch_match_server(const uint32_t* ops, int32_t* hdr, uint32_t last, int32_t launch_id, unsigned long long idle_ticks,
-                               hipStream_t s);
+                               unsigned long long life_ticks, hipStream_t s);
 hipError_t launch_match_two_small(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t max_dist,
                                   int32_t* hits, int32_t seq, hipStream_t s);
 

@@ -312,13 +312,18 @@ __global__ __launch_bounds__(256) void k_match_two_small(const uint32_t* __restr
 // server launch that has exited, [4..5] the 64-bit request word (below).
 constexpr uint32_t kServerLanes = 1024;  // 16 waves: the operands' loads and the na x nb compares spread over four times the lanes
 // request word (ONE 64-bit load per poll brings everything): seq (21 bits) << 43 | max_dist (9) << 32 | na (16) << 16 | nb (16)
+// life_ticks: the workgroup also leaves after this long whatever the traffic, and the host starts the next one: a device-wide
+// wait of ANOTHER thread (hipFree, hipMalloc, hipDeviceSynchronize) waits for kernels in flight, and a search loop that calls
+// back to back for seconds would otherwise hold it off for as long.
 __global__ __launch_bounds__(kServerLanes) void k_match_server(const uint32_t* __restrict__ ops, int32_t* hdr, uint32_t last,
-                                                               int32_t launch_id, unsigned long long idle_ticks, uint32_t max_polls) {
+                                                               int32_t launch_id, unsigned long long idle_ticks,
+                                                               unsigned long long life_ticks, uint32_t max_polls) {
     extern __shared__ uint32_t sm[];
     __shared__ uint32_t s_qt[2];
     __shared__ unsigned long long s_req;
     unsigned long long* req = reinterpret_cast<unsigned long long*>(hdr + 4);
     unsigned long long t_idle = wall_clock64();
+    const unsigned long long t_born = t_idle;
     for (;;) {
         if (threadIdx.x == 0) {
             unsigned long long w = 0;
@@ -326,7 +331,9 @@ __global__ __launch_bounds__(kServerLanes) void k_match_server(const uint32_t* _
             for (uint32_t polls = 0; polls < max_polls; ++polls) {
                 w = __hip_atomic_load(req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                 got = (uint32_t)(w >> 43) != last;
-                if (got || wall_clock64() - t_idle > idle_ticks) break;
+                const unsigned long long now = wall_clock64();
+                if (got || now - t_idle > idle_ticks) break;
+                if (now - t_born > life_ticks) break;  // (between two requests only: a request that was seen is always answered)
                 __builtin_amdgcn_s_sleep(1);
             }
             s_req = got ? w : ~0ull;
@@ -439,7 +446,7 @@ uint32_t match_two_small_limit() { return kMatchSmallBytes; }
 
 // one resident workgroup serving hvd_match_two calls out of pinned host memory (k_match_server, above)
 hipError_t launch_match_server(const uint32_t* ops, int32_t* hdr, uint32_t last, int32_t launch_id, unsigned long long idle_ticks,
-                               hipStream_t s) {
+                               unsigned long long life_ticks, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = kMatchSmallBytes;  // 40 B per frame hash of both operands at most
     if (!attr_set) {
@@ -447,7 +454,7 @@ hipError_t launch_match_server(const uint32_t* ops, int32_t* hdr, uint32_t last,
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_match_server, dim3(1), dim3(kServerLanes), lds, s, ops, hdr, last, launch_id, idle_ticks, 4000000u);
+    hipLaunchKernelGGL(k_match_server, dim3(1), dim3(kServerLanes), lds, s, ops, hdr, last, launch_id, idle_ticks, life_ticks, 4000000u);
     return hipGetLastError();
 }
 

@@ -371,5 +371,26 @@ def test_match_server_answers_like_the_per_call_kernel_and_the_oracle(gpu, hvd, 
         d = hvd.calculate_distance(blobs[3], blobs[3])
         assert d == (1 if len(blobs[3]) else 101)
         gpu.check(lib.hvd_device_synchronize())  # returns: the server leaves by itself
+        # a search loop that calls back to back must not hold off another thread's device-wide waits (hipMalloc / hipFree wait
+        # for kernels in flight): the server's lifetime is bounded, the next call starts the next one
+        stop, stalls = threading.Event(), []
+
+        def caller():
+            while not stop.is_set():
+                hvd.vpdq.match_counts(blobs[3], blobs[4], 31)
+
+        th = threading.Thread(target=caller)
+        th.start()
+        try:
+            t_end = time.perf_counter() + 0.5
+            while time.perf_counter() < t_end:
+                t0 = time.perf_counter()
+                buf = gpu.DeviceBuffer(1 << 20)
+                buf.free()
+                stalls.append(time.perf_counter() - t0)
+        finally:
+            stop.set()
+            th.join()
+        assert len(stalls) > 20 and max(stalls) < 0.1, (len(stalls), max(stalls))
     finally:
         gpu.check(lib.hvd_debug_set(b"match_server", 1))
