@@ -19,6 +19,12 @@
 #include "copy_pool.h"
 #include "hvd_kernels.h"
 
+// HVD_ABL_STREAM_NOHASH: timing-only ablation (WRONG RESULTS: batches are uploaded, nothing is hashed) -- is the upload rate of
+// the pipeline held back by the kernels that run beside it? Like every ablation it needs -DHVD_DEV_ABLATION as well.
+#if defined(HVD_ABL_STREAM_NOHASH) && !defined(HVD_DEV_ABLATION)
+#error "HVD_ABL_STREAM_NOHASH is a developer ablation build (wrong results): add -DHVD_DEV_ABLATION to confirm"
+#endif
+
 namespace hvd {
 int api_fail(int code, const char* fmt, ...);     // hvd_api.cpp
 const float* api_dct_device();                    // hvd_api.cpp; nullptr before hvd_init
@@ -32,7 +38,10 @@ hipError_t api_launch_hash(const void* d_frames, int64_t n, int h, int w, int ch
 
 namespace {
 
-constexpr int kSlots = 3;
+// Six slots of (by default) 32 MiB: a slot is refilled only when its previous batch has been hashed and read back, and the kernels
+// of a small batch take ~0.25 ms whatever its size -- with three slots of 64 MiB the uploads of the two batches behind it did not
+// always cover that (round 5: hash_frame(bytes) 16.9 -> 15.9 us per 512x512 frame, within 2 % of the zero-copy feed).
+constexpr int kSlots = 6;
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -92,13 +101,17 @@ struct hvd_hasher {
 
 // A video starts on an empty pipeline (the reference makes one hasher per video and finish() drains it, vpdqpy/vpdqpy.py:113-119):
 // with full 64 MiB batches the DMA engine idled for the whole first batch's fill time at the start of every video -- 0.94 ms of a
-// 5.5 ms video of 300 frames at 512x512 (profiles/r05_vh_where.txt). The first batch of a video is therefore SMALL (8 MiB of
-// frames) and the batch size doubles from submit to submit up to the slot's capacity; finish() starts the ramp again. Frames of
-// 4 KB never leave the first step (2048 of them), so the small-frame path still submits once per video.
+// 5.5 ms video of 300 frames at 512x512 (profiles/r05_vh_where.txt). The first batch of a video is therefore SMALL (4 MiB of
+// frames) and the batch size GROWS from submit to submit up to the slot's capacity; finish() starts the ramp again. The growth
+// factor matters: the engine uploads batch k while the host fills batch k+1, and the host (4 copy threads: ~10 us per 786 KB
+// frame) is only 1.4x faster than the link (13.7 us) -- doubling made every batch of the ramp take longer to fill than its
+// predecessor took to upload (0.44 ms of idle link per video); x 1.25 keeps the link busy. Frames of 4 KB never leave the first
+// step (1024 of them), so the small-frame path still submits once per video.
 static int64_t first_limit(const hvd_hasher* hs) {
-    const int64_t f = (int64_t)(((size_t)8 << 20) / hs->frame_bytes);
+    const int64_t f = (int64_t)(((size_t)4 << 20) / hs->frame_bytes);
     return std::max<int64_t>(1, std::min<int64_t>(hs->batch, f));
 }
+static int64_t next_limit(const hvd_hasher* hs) { return std::min<int64_t>(hs->batch, hs->limit + std::max<int64_t>(1, hs->limit / 4)); }
 
 // A hasher lives on the context it was created on, whatever context the calling thread has selected.
 namespace {
@@ -135,18 +148,20 @@ static int submit(hvd_hasher* hs, Slot& s) {
     NsScope ns(g_ns_submit);
     const int64_t m = s.filled;
     S_TRY(hipMemcpyAsync(s.d_frames, s.h_frames, hs->frame_bytes * (size_t)m, hipMemcpyHostToDevice, s.stream));
+#ifndef HVD_ABL_STREAM_NOHASH
     S_TRY(hvd::api_launch_hash(s.d_frames, m, hs->h, hs->w, hs->channels, s.d_scratch, s.d_hashes, s.d_quality, s.stream));
+#endif
     S_TRY(hipMemcpyAsync(s.h_hashes, s.d_hashes, 32 * (size_t)m, hipMemcpyDeviceToHost, s.stream));
     S_TRY(hipMemcpyAsync(s.h_quality, s.d_quality, 4 * (size_t)m, hipMemcpyDeviceToHost, s.stream));
     S_TRY(hipEventRecord(s.done, s.stream));
     s.in_flight = m;
     s.filled = 0;
-    hs->limit = std::min<int64_t>(hs->batch, 2 * hs->limit);
+    hs->limit = next_limit(hs);
     return HVD_OK;
 }
 
 // The reference creates one VideoHasher per video (vpdqpy/vpdqpy.py:113) and videos come strictly one after the
-// other (dedup.py:346-352). Pinning and unpinning 3 x 64 MiB of host memory per video costs more than hashing a
+// other (dedup.py:346-352). Pinning and unpinning 6 x 32 MiB of host memory per video costs more than hashing a
 // short video, so a destroyed hasher's slots (pinned staging, device buffers, streams, events) are PARKED and the
 // next hvd_hasher_create with the same geometry takes them over. At most kMaxParked sets are kept (a GUI worker
 // and the CLI never run more than one or two hashers at a time); hvd_shutdown() releases them.

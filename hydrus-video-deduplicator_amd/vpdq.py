@@ -151,7 +151,7 @@ class VideoHasher:
     (0 = library default). One hasher per decoder thread."""
 
     def __init__(self, average_fps: int, width: int, height: int, num_threads: int = 0,
-                 batch_bytes: int = 64 << 20):
+                 batch_bytes: int = 32 << 20):
         if width < 64 or height < 64:
             raise ValueError("frames must be at least 64x64")
         self.average_fps = average_fps

@@ -8,6 +8,7 @@ NAME=$1; UNIT=$2; shift 2
 ROOT=$(cd "$(dirname "$0")/.." && pwd); SRC=$ROOT/hydrus-video-deduplicator_amd/csrc; OUT=$ROOT/build_tmp; mkdir -p $OUT
 make -C $SRC -s
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950"
+# (.cpp units go through hipcc too: csrc/Makefile)
 ( cd $SRC && /opt/rocm/bin/hipcc $FLAGS "$@" -c $UNIT -o $OUT/${UNIT%.*}_$NAME.o )
 OBJS=""
 for o in hvd_api hvd_stream k_hamming k_hamming_mfma k_vmatch k_synth k_pdq; do
