@@ -202,7 +202,7 @@ def videohasher_stream_leg(lib, L, synth, vpdq):
         nt_level = C.c_int(0)
         L.check(lib.hvd_debug_get(b"copy_nt", C.byref(nt_level)))
         res["copy_nt_level"] = {0: "plain memcpy", 2: "AVX2 streaming stores", 3: "AVX-512 streaming stores"}.get(nt_level.value, "?")
-        for feed in ("bytes", "bytes_memcpy", "buffer", "acquire_copy", "acquire_only", "acquire_run"):
+        for feed in ("bytes", "bytes_memcpy", "buffer", "acquire_only", "acquire_copy", "acquire_run"):  # (fast feeds first)
             if feed == "bytes_memcpy":
                 if ch != 3 or nt_level.value == 0:
                     continue
@@ -214,7 +214,7 @@ def videohasher_stream_leg(lib, L, synth, vpdq):
             else:
                 assert run(real).bytes == want  # warm-up
                 expect = want
-            for _ in range(2):  # two untimed videos of the feed itself: after a slow leg (acquire_copy: the GPU mostly idle) the
+            for _ in range(4):  # four untimed videos of the feed itself: after a slow leg (acquire_copy: the GPU mostly idle) the
                 run(real)       # first videos of a fast one ran 40 % slower (clocks / DMA state), an order artefact
             t = time.perf_counter()
             for _ in range(n_videos):
