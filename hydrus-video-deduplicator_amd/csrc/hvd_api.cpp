@@ -1051,6 +1051,8 @@ int run_on_group(const std::function<int(int)>& fn) {
     t_ctx = saved;
     for (std::thread& t : th) t.join();
     (void)need_ready();
+    g_hx.rearm();  // (everybody has left: a barrier broken by this call's own failure -- or by an overflow verdict, which every rank
+                   // reaches together -- must not fail the next exchange of callers that drive the contexts from their own threads)
     for (int i = 0; i < n; ++i)
         if (rc[(size_t)i] != HVD_OK) {
             snprintf(g_err, sizeof g_err, "%s", msg[(size_t)i].c_str());
