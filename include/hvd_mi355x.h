@@ -165,7 +165,7 @@ int hvd_hasher_set_threads(hvd_hasher* hs, int n);
 int hvd_hasher_acquire(hvd_hasher* hs, uint8_t** out_frame);
 int hvd_hasher_commit(hvd_hasher* hs);
 /* The same for a run of frames: *out_frames is where the next frames belong, back to back, *out_n (1 <= *out_n <= want)
- * how many fit there (what is left of the current batch slot); hvd_hasher_commit_n(n) makes the first n count
+ * how many fit there (what is left of the current batch: batches start small and grow per video); hvd_hasher_commit_n(n) makes the first n count
  * (0 <= n <= *out_n). One FFI round trip per run instead of two per frame: what a decoder of small frames wants. */
 int hvd_hasher_acquire_n(hvd_hasher* hs, int64_t want, uint8_t** out_frames, int64_t* out_n);
 int hvd_hasher_commit_n(hvd_hasher* hs, int64_t n);
@@ -219,6 +219,9 @@ int hvd_get_pdq_dct_mode(void);
  *   "vmatch_exchange" 0|1|2                                (key exchange of the video search: iff world > 1 | always | never)
  *   "vmatch_slots_log2" 0|4..30                            (initial size of the video-reduction tables; tests the regrowth)
  *   "vmatch_variant" 0|8..19                               (all-pairs form of the video-level searches; 0 = the auto variant)
+ *   "match_server" 0|1                                     (hvd_match_two, small operands: one launch per call | a workgroup that stays
+ *                                                           resident between calls and polls pinned host memory -- the default)
+ *   "copy_nt" 0|1                                          (hvd_hasher_push: plain memcpy | non-temporal stores where the CPU has them)
  * Unknown keys and out-of-range values return HVD_ERR_ARG. */
 int hvd_debug_set(const char* key, int value);
 /* "mfma_auto_form": the form (9, 18 or 12; 15..19 if "mfma_auto_mid" says so) the last auto-variant launch ran;
@@ -228,7 +231,9 @@ int hvd_debug_set(const char* key, int value);
  * "vmatch_us_local" / "vmatch_us_exchange" / "vmatch_us_fold": host microseconds of the three phases of the last video-level
  * search on the calling thread's context (local: packed hashes, probe, all-pairs pass, key set; exchange: agreement words,
  * all-gather of the key lists, merged set -- 0 at world 1; fold: keys -> pair map). "copy_nt": 0 | 2 | 3 = plain memcpy |
- * AVX2 | AVX-512 streaming stores in hvd_hasher_push (hvd_debug_set "copy_nt" 0|1; HVD_COPY_NT=0 in the environment). */
+ * AVX2 | AVX-512 streaming stores in hvd_hasher_push (hvd_debug_set "copy_nt" 0|1; HVD_COPY_NT=0 in the environment).
+ * "hasher_us_copy" / "hasher_us_submit" / "hasher_us_wait": host microseconds the streaming hashers of this process spent copying
+ * frames into the ring, enqueueing batches and waiting for a slot since the last read (reading clears). */
 int hvd_debug_get(const char* key, int* out_value);
 
 /* Bytes of device scratch hvd_dev_pdq_hash_frames needs for this geometry (0 for
