@@ -90,7 +90,8 @@ struct Ctx {
     // allocated or freed per call once the sizes have been seen (h_mu serialises the users)
     enum Scr {
         S_DB, S_IMG, S_GRP, S_PAIRS, S_DB2, S_IMG2, S_GRP2, S_VIDQ, S_VIDT, S_OFF, S_SET, S_SET2, S_PKEYS, S_PCNT, S_LIST,
-        S_LISTALL, S_VOUT, S_FRAMES, S_FSCR, S_HASH, S_QUAL, S_COMPACT, S_COUNTERS, S_BITS, S_BITS2, S_N
+        S_LISTALL, S_VOUT, S_FRAMES, S_FSCR, S_HASH, S_QUAL, S_COMPACT, S_COUNTERS, S_BITS, S_BITS2, S_BROWS, S_BCOOC, S_BITS_O, S_BITS2_O,
+        S_IMG_O, S_IMG2_O, S_N
     };
     void* scr[S_N] = {};
     size_t scr_cap[S_N] = {};
@@ -99,6 +100,8 @@ struct Ctx {
     int v_fail_rank = 0;              // hvd_debug_set("vmatch_fail_rank"): rank + 1 whose local phase fails (tests the agreement step)
     int v_force_slots_log2 = 0;       // hvd_debug_set("vmatch_slots_log2"): start the tables this small (tests the regrowth)
     int v_variant = 0;                // hvd_debug_set("vmatch_variant"): all-pairs form of the video-level searches, 0 = default (tests, fuzz)
+    int v_bit_order = 1;              // hvd_debug_set("vmatch_bit_order"): data-dependent bit order of the video search: 0 never, 1 from 65 536 frames on, 2 always
+    int v_bit_order_used = 0;         // the last video search on this context rewrote its hashes in a chosen bit order
     std::recursive_mutex h_mu;
 };
 constexpr int kMaxCtx = 16;
@@ -749,6 +752,11 @@ int hvd_debug_set(const char* key, int value) {
         for (int k = 0; k < g_nctx; ++k) g_ctx[k].v_variant = value;
         return HVD_OK;
     }
+    if (strcmp(key, "vmatch_bit_order") == 0) {  // data-dependent bit order of the video search: 0 never, 1 from 65 536 frames on (default), 2 always
+        if (value < 0 || value > 2) return fail(HVD_ERR_ARG, "vmatch_bit_order: 0 | 1 | 2");
+        for (int k = 0; k < std::max(1, g_nctx); ++k) g_ctx[k].v_bit_order = value;
+        return HVD_OK;
+    }
 #ifndef HVD_NO_BENCH_SYMBOLS
     if (strcmp(key, "vmatch_fail_rank") == 0) {  // tests only (include/hvd_mi355x_bench.h): rank (value - 1) fails before the key exchange; 0 = off
         for (int k = 0; k < g_nctx; ++k) g_ctx[k].v_fail_rank = value;
@@ -809,6 +817,10 @@ int hvd_debug_get(const char* key, int* out_value) {
             *out_value = (int)v[k];
             return HVD_OK;
         }
+    if (strcmp(key, "vmatch_bit_order_used") == 0) {
+        *out_value = g.v_bit_order_used;
+        return HVD_OK;
+    }
     {
         const char* vk[3] = {"vmatch_us_local", "vmatch_us_exchange", "vmatch_us_fold"};
         for (int k = 0; k < 3; ++k)
@@ -1429,6 +1441,55 @@ int read_counters(unsigned long long* d_counters, unsigned long long out[4]) {
     return HVD_OK;
 }
 
+// Which 128 bits should the first stage see? (k_hamming_mfma.hip: "data-dependent bit order".) From the co-occurrence counts of a
+// strided sample of the packed hashes: Pearson correlation of every pair of bits, then 128 times drop the bit whose summed
+// |correlation| with the bits still in the set is largest (a constant bit goes first). perm = the 128 kept bits in ascending
+// order, then the dropped ones: bit k of a rewritten hash is bit perm[k] of the original. Deterministic in the data, so every rank
+// of a sharded search -- the library is replicated -- arrives at the same order. *changed = false: too few hashes, keep the order.
+int choose_bit_order(const void* d_bits, uint32_t n, bool always, uint8_t perm[256], bool* changed) {
+    *changed = false;
+    for (int k = 0; k < 256; ++k) perm[k] = (uint8_t)k;
+    const uint32_t sample = std::min<uint32_t>(n, 16384u) & ~63u;
+    if (sample < (always ? 64u : 4096u)) return HVD_OK;
+    const uint32_t words = sample / 64u, stride = n / sample;
+    void *d_rows = nullptr, *d_cooc = nullptr;
+    SCR(S_BROWS, 8 * 256 * (size_t)words, d_rows);
+    SCR(S_BCOOC, 4 * 256 * 256, d_cooc);
+    HIP_TRY(hvd::launch_bit_cooc(d_bits, stride, words, d_rows, d_cooc, g.stream));
+    std::vector<uint32_t> cooc(256 * 256);
+    HIP_TRY(hipMemcpyAsync(cooc.data(), d_cooc, 4 * cooc.size(), hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    const double N = (double)sample;
+    std::vector<double> pr(256), sd(256), a(256 * 256, 0.0), load(256, 0.0);
+    for (int i = 0; i < 256; ++i) {
+        pr[i] = cooc[(size_t)i * 257] / N;
+        sd[i] = std::sqrt(std::max(0.0, pr[i] * (1.0 - pr[i])));
+    }
+    for (int i = 0; i < 256; ++i)
+        for (int j = 0; j < 256; ++j) {
+            if (i == j) continue;
+            const double r = (sd[i] < 1e-6 || sd[j] < 1e-6) ? 1.0 : (cooc[(size_t)i * 256 + j] / N - pr[i] * pr[j]) / (sd[i] * sd[j]);
+            a[(size_t)i * 256 + j] = std::fabs(r);
+            load[i] += std::fabs(r);
+        }
+    bool in[256];
+    for (int i = 0; i < 256; ++i) in[i] = true;
+    for (int step = 0; step < 128; ++step) {
+        int worst = -1;
+        for (int i = 0; i < 256; ++i)
+            if (in[i] && (worst < 0 || load[i] >= load[worst])) worst = i;  // (ties: the higher bit goes)
+        in[worst] = false;
+        for (int j = 0; j < 256; ++j) load[j] -= a[(size_t)worst * 256 + j];
+    }
+    int k = 0;
+    for (int i = 0; i < 256; ++i)
+        if (in[i]) perm[k++] = (uint8_t)i;
+    for (int i = 0; i < 256; ++i)
+        if (!in[i]) perm[k++] = (uint8_t)i;
+    for (int i = 0; i < 256; ++i) *changed = *changed || perm[i] != i;
+    return HVD_OK;
+}
+
 // All-pairs pass in video mode -> set of (frame, video) keys -> [key exchange between ranks] -> pair map with
 // the vPDQ counters, left in the pool for vmatch_emit. Overflowing tables are rebuilt larger and only the
 // step that overflowed is repeated; the inputs never move.
@@ -1448,11 +1509,42 @@ int vmatch_build(const VmArgs& v) {
     SCR(S_COUNTERS, 64, d_counters);
     // the pair-queue form of the all-pairs kernel settles its candidates on PACKED hashes; this entry is handed images only
     void *d_bits_t = nullptr, *d_bits_q = nullptr;
+    const void *img_t = v.d_img_t, *img_q = v.d_img_q;
     SCR(S_BITS, 32 * (size_t)v.nt, d_bits_t);
     HIP_TRY(hvd::launch_pack_fp4(v.d_img_t, v.nt, d_bits_t, g.stream));
     if (v.rect) {
         SCR(S_BITS2, 32 * (size_t)v.nq, d_bits_q);
         HIP_TRY(hvd::launch_pack_fp4(v.d_img_q, v.nq, d_bits_q, g.stream));
+    }
+    // Round 5: the search runs on hashes rewritten in a bit order chosen from the library itself (choose_bit_order): the first
+    // stage then sees the 128 least entangled bits. Library scratch only -- the caller's image is left as it is -- and the
+    // same order for rows and columns, so every distance, and with it every record, is what it was.
+    g.v_bit_order_used = 0;
+    if (g.v_bit_order == 2 || (g.v_bit_order == 1 && v.nt >= 65536u)) {
+        uint8_t perm[256];
+        bool changed = false;
+        if (int rc = choose_bit_order(d_bits_t, v.nt, g.v_bit_order == 2, perm, &changed)) return rc;
+        if (changed) {
+            size_t img_bytes = 0;
+            void *d_bo = nullptr, *d_io = nullptr;
+            if (int rc = hvd_fp4_image_bytes((int64_t)v.nt, &img_bytes)) return rc;
+            SCR(S_BITS_O, 32 * (size_t)v.nt, d_bo);
+            SCR(S_IMG_O, img_bytes, d_io);
+            HIP_TRY(hvd::launch_reorder_bits(d_bits_t, v.nt, perm, d_bo, d_io, g.stream));
+            d_bits_t = d_bo;
+            img_t = d_io;
+            if (v.rect) {
+                if (int rc = hvd_fp4_image_bytes((int64_t)v.nq, &img_bytes)) return rc;
+                SCR(S_BITS2_O, 32 * (size_t)v.nq, d_bo);
+                SCR(S_IMG2_O, img_bytes, d_io);
+                HIP_TRY(hvd::launch_reorder_bits(d_bits_q, v.nq, perm, d_bo, d_io, g.stream));
+                d_bits_q = d_bo;
+                img_q = d_io;
+            } else {
+                img_q = img_t;
+            }
+            g.v_bit_order_used = 1;
+        }
     }
     const unsigned long long frames = (unsigned long long)v.nt + (v.rect ? v.nq : 0u);
     slots = pow2_at_least(std::max<unsigned long long>(1ull << 16, 4ull * frames));
@@ -1480,8 +1572,8 @@ int vmatch_build(const VmArgs& v) {
         a.col_chunk = 0;
         a.ctx_id = t_ctx;
         a.sink = hvd::VideoSink{d_set, slots - 1, d_counters, v.d_vid_q, v.d_vid_t};
-        hipError_t e = v.rect ? hvd::launch_cross_mfma(a, v.d_img_q, v.nq, v.d_img_t, v.d_excl_t, g.stream)
-                              : hvd::launch_allpairs_mfma(a, v.d_img_t, g.stream);
+        hipError_t e = v.rect ? hvd::launch_cross_mfma(a, img_q, v.nq, img_t, v.d_excl_t, g.stream)
+                              : hvd::launch_allpairs_mfma(a, img_t, g.stream);
         if (e != hipSuccess) return fail(HVD_ERR_HIP, "video-level all-pairs launch: %s", hipGetErrorString(e));
         if (int rc = read_counters(d_counters, c)) return rc;
         if (c[0] == 0) break;

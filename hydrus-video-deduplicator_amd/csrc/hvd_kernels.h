@@ -41,6 +41,9 @@ extern int g_mfma_force_sel;
 extern uint32_t g_fp4_code;
 hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s);
 hipError_t launch_pack_fp4(const void* d_img, uint32_t n, void* d_db, hipStream_t s);  // image -> packed 32-byte hashes
+// data-dependent bit order of the video search (k_hamming_mfma.hip): co-occurrence counts of a strided sample, and the rewrite
+hipError_t launch_bit_cooc(const void* d_bits, uint32_t stride, uint32_t words, void* d_rows, void* d_cooc, hipStream_t s);
+hipError_t launch_reorder_bits(const void* d_bits_in, uint32_t n, const uint8_t perm[256], void* d_bits_out, void* d_img, hipStream_t s);
 hipError_t launch_allpairs_mfma(const AllPairsArgs& a, const void* d_img, hipStream_t s);
 // a.n / a.d_group describe the target set; rows are the nq query hashes (image d_img_q, groups a.d_group
 // for queries and d_group_t for targets; pass both or neither).

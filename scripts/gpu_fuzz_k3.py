@@ -46,6 +46,7 @@ for seed in range(first, first + nseeds):
     tol = int(rng.choice([31, 31, 31, 0, 20, 63]))
     want = O.match_videos(fr, off, tol)
     L.check(lib.hvd_debug_set(b"mfma_force_sel", int(rng.choice([-1, 0, 1, 2]))))  # round 5: the first stage's 128 bits
+    L.check(lib.hvd_debug_set(b"vmatch_bit_order", int(rng.choice([0, 2, 2]))))    # ... and the data-dependent bit order
     res = {}
     for v in FORMS:
         L.check(lib.hvd_debug_set(b"vmatch_variant", v))
@@ -74,5 +75,6 @@ for seed in range(first, first + nseeds):
                 print(f"CROSS MISMATCH seed {seed}: V={V} n={n} kind={kind} tol={tol} form={v}: got {len(got)} want {len(exp)}", flush=True)
     L.check(lib.hvd_debug_set(b"vmatch_variant", 0))
     L.check(lib.hvd_debug_set(b"mfma_force_sel", -1))
+    L.check(lib.hvd_debug_set(b"vmatch_bit_order", 1))
 print(f"{nseeds} seeds from {first}: {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

@@ -425,3 +425,49 @@ def test_timer_marks_split_a_sequence_without_extra_synchronisation(gpu, hvd):
     finally:
         for b in (d_db, d_img, d_pairs, d_cnt):
             b.free()
+
+
+# ------------------------------------------------------------------ K3: data-dependent bit order of the video search ----------
+
+def test_video_search_in_a_chosen_bit_order_returns_the_same_records(gpu, hvd, oracle):
+    """The video search rewrites its hashes in a bit order chosen from the library (the 128 least entangled bits first: the
+    first stage lets fewer unrelated frames through). Hamming distance does not depend on the order, so the records must be
+    identical with the rewrite off, automatic and forced -- symmetric and query x target form, every queue form, against the
+    oracle; and on hashes with real structure (every second DCT row a copy of its neighbour + noise) the rewrite must happen."""
+    lib = gpu.load()
+
+    def used():
+        v = C.c_int(0)
+        gpu.check(lib.hvd_debug_get(b"vmatch_bit_order_used", C.byref(v)))
+        return v.value
+
+    rng = np.random.default_rng(97)
+    fr, off, _ = hvd.synth.video_hashes(700, seed=98, frames_per_video=(1, 40), copy_fraction=0.3)
+    # structure: bytes 2k+1 mostly repeat byte 2k (entangled bit pairs), so that some orders are better than others
+    noise = (rng.random(fr[:, 1::2].shape) < 0.1) * rng.integers(0, 256, fr[:, 1::2].shape)
+    fr[:, 1::2] = fr[:, 0::2] ^ noise.astype(np.uint8)
+    want = oracle.match_videos(fr, off, 31, num_threads=8)
+    assert len(want) > 50
+    q_sel = np.arange(0, 700, 5)
+    q_off = np.zeros(q_sel.size + 1, dtype=np.int64)
+    np.cumsum(np.diff(off)[q_sel], out=q_off[1:])
+    q_fr = np.concatenate([fr[off[v]:off[v + 1]] for v in q_sel])
+    try:
+        got_x = {}
+        for mode in (0, 2, 1):
+            gpu.check(lib.hvd_debug_set(b"vmatch_bit_order", mode))
+            for v in (0, 18, 15, 12, 9, 8):
+                gpu.check(lib.hvd_debug_set(b"vmatch_variant", v))
+                assert np.array_equal(hvd.match_videos(fr, off, 31), want), (mode, v)
+                assert used() == (1 if mode == 2 else 0), (mode, used())  # (14 k frames: the automatic mode leaves small libraries alone)
+            gpu.check(lib.hvd_debug_set(b"vmatch_variant", 0))
+            got_x[mode] = hvd.search.match_videos_cross(q_fr, q_off, fr, off, ids_q=q_sel.astype(np.int32), ids_t=np.arange(700, dtype=np.int32))
+        assert np.array_equal(got_x[0], got_x[2]) and np.array_equal(got_x[0], got_x[1]) and len(got_x[0]) > 10
+        # tolerances around the first stage's limits, in the chosen order
+        gpu.check(lib.hvd_debug_set(b"vmatch_bit_order", 2))
+        for tol in (0, 5, 63, 64, 100):
+            assert np.array_equal(hvd.match_videos(fr[:off[200]], off[:201], tol),
+                                  oracle.match_videos(fr[:off[200]], off[:201], tol, num_threads=8)), tol
+    finally:
+        gpu.check(lib.hvd_debug_set(b"vmatch_variant", 0))
+        gpu.check(lib.hvd_debug_set(b"vmatch_bit_order", 1))
