@@ -661,6 +661,11 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                 lib5.free()
             fv5 = C.c_int(0)
             L.check(lib.hvd_debug_get(b"mfma_auto_form", C.byref(fv5)))
+            probe5 = {}
+            for key_ in ("vmatch_bit_order_used", "mfma_auto_half", "mfma_probe_survivors", "mfma_probe_survivors_hi", "mfma_probe_survivors_mix"):
+                pv_ = C.c_int(0)
+                L.check(lib.hvd_debug_get(key_.encode(), C.byref(pv_)))
+                probe5[key_] = pv_.value
             d_frames.free()
             d_copy.free()
             planted5 = {(int(min(s, d)), int(max(s, d))) for d, s in enumerate(copy_of) if s >= 0}
@@ -682,6 +687,12 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             flop5 = exec_cmp5 / 1024.0 * 2.0 * 131072.0
             search5 = {"ms": round(search5_ms, 3), "ms_sd": round(search5_sd, 3), "form": int(fv5.value),
                        "form_name": {9: "fetch", 12: "register cascade", 15: "pair queue (group masks)", 18: "pair queue (panel marks)"}.get(int(fv5.value), "?"),
+                       "first_stage": {"bit_order_chosen_from_the_library": bool(probe5["vmatch_bit_order_used"]),
+                                       "selection": {0: "bits 0..127", 1: "bits 128..255", 2: "bits 0..63 + 192..255"}.get(probe5["mfma_auto_half"], "?")
+                                                    + (" of the rewritten hashes" if probe5["vmatch_bit_order_used"] else ""),
+                                       "probe_survivors_of_16.7M_sampled_pairs": {"bits 0..127": probe5["mfma_probe_survivors"],
+                                                                                  "bits 128..255": probe5["mfma_probe_survivors_hi"],
+                                                                                  "bits 0..63 + 192..255": probe5["mfma_probe_survivors_mix"]}},
                        "frame_comparisons_per_s": sig(fcmp5 / (search5_ms * 1e-3)),
                        "executed_comparisons_per_s": sig(exec_cmp5 * world / (search5_ms * 1e-3)),
                        "note": "HIP-event time of the whole hvd_dev_vpdq_match_videos call on the library stream (packed hashes, "

@@ -219,6 +219,8 @@ int hvd_get_pdq_dct_mode(void);
  *   "vmatch_exchange" 0|1|2                                (key exchange of the video search: iff world > 1 | always | never)
  *   "vmatch_slots_log2" 0|4..30                            (initial size of the video-reduction tables; tests the regrowth)
  *   "vmatch_variant" 0|8..19                               (all-pairs form of the video-level searches; 0 = the auto variant)
+ *   "vmatch_bit_order" 0|1|2                               (video search: hashes rewritten with the 128 least entangled bits first: never |
+ *                                                           from 65 536 frames on (default) | always; results never change)
  *   "match_server" 0|1                                     (hvd_match_two, small operands: one launch per call | a workgroup that stays
  *                                                           resident between calls and polls pinned host memory -- the default)
  *   "copy_nt" 0|1                                          (hvd_hasher_push: plain memcpy | non-temporal stores where the CPU has them)
@@ -232,6 +234,7 @@ int hvd_debug_set(const char* key, int value);
  * search on the calling thread's context (local: packed hashes, probe, all-pairs pass, key set; exchange: agreement words,
  * all-gather of the key lists, merged set -- 0 at world 1; fold: keys -> pair map). "copy_nt": 0 | 2 | 3 = plain memcpy |
  * AVX2 | AVX-512 streaming stores in hvd_hasher_push (hvd_debug_set "copy_nt" 0|1; HVD_COPY_NT=0 in the environment).
+ * "vmatch_bit_order_used": 1 if the last video search on this context rewrote its hashes in a chosen bit order.
  * "hasher_us_copy" / "hasher_us_submit" / "hasher_us_wait": host microseconds the streaming hashers of this process spent copying
  * frames into the ring, enqueueing batches and waiting for a slot since the last read (reading clears). */
 int hvd_debug_get(const char* key, int* out_value);
