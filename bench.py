@@ -752,6 +752,11 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             print(f"[bench] rank {rank}: {extras_note}", file=sys.stderr)
             hard_exit = True
     cfg4, cfg5 = extras.get("cfg4"), extras.get("cfg5")
+    cfg5_note = None
+    if cfg5 is None and not args.no_extras and not extras_note and world > 1 and exchange is None:
+        # (said out loud: a line without config5 must be readable as "skipped, and why", not as a failure)
+        cfg5_note = ("config5 leg skipped: its hash-shard and key-list exchanges run inside the library over RCCL, and this run "
+                     f"exchanges over {exchange_kind}")
 
     if rank != 0:
         if extras_note:  # do not enter another collective: rank 0 prints what it has
@@ -841,6 +846,8 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         out["config5"] = cfg5
     if extras_note:
         out["extras_note"] = extras_note
+    if cfg5_note:
+        out["config5_note"] = cfg5_note
 
     cpu = None
     if world == 1 and not args.no_extras:
