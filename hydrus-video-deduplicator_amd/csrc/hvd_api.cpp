@@ -53,6 +53,11 @@ int fail(int code, const char* fmt, ...) {
         if (r_ != ncclSuccess) return fail(HVD_ERR_RCCL, "%s: %s", #expr, ncclGetErrorString(r_)); \
     } while (0)
 
+// Multi-process GPU work on hosts whose driver only supports dmabuf IPC needs HSA_ENABLE_IPC_MODE_LEGACY=0 (without it RCCL's
+// hipIpcGetMemHandle fails with "invalid argument"). The variable is read when the HSA runtime starts, i.e. at the first HIP
+// call: set it when the library is loaded, never over a value the user chose.
+__attribute__((constructor)) void hvd_default_ipc_mode() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", /*overwrite=*/0); }
+
 struct Ctx {
     bool ready = false;
     int device = -1;

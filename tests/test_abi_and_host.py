@@ -301,3 +301,20 @@ def test_thread_rendezvous_is_a_rendezvous():
         t.join(60)
     assert out[0] is not None and out[0] == out[1] == out[2]
     assert out[0][0] == [b"\x00\x00", b"\x01\x00", b"\x02\x00"] and out[0][1] == [2.0, 0.0, 0.0] and out[0][3] == b"x0"
+
+
+def test_library_load_defaults_the_ipc_mode_without_overriding_the_user():
+    """Hosts whose driver only supports dmabuf IPC need HSA_ENABLE_IPC_MODE_LEGACY=0 for RCCL between processes; the library
+    sets it when it is loaded (before the HSA runtime starts) unless the user chose a value."""
+    import subprocess
+    import sys
+
+    code = ("import ctypes as C, os, sys; sys.path.insert(0, %r); import hvd_amd._lib as L; L.load(); "
+            "g = C.CDLL(None).getenv; g.restype = C.c_char_p; print((g(b'HSA_ENABLE_IPC_MODE_LEGACY') or b'unset').decode())" % ROOT)
+    for preset, want in ((None, "0"), ("1", "1")):
+        env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+        if preset is not None:
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = preset
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        assert r.stdout.decode().strip().splitlines()[-1] == want
