@@ -418,7 +418,12 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
 
     variant = search.DEFAULT_VARIANT if args.variant < 0 else args.variant
     # what the ranks run on: versions, library paths, every rank's device, the peer links between them (xGMI or PCIe)
-    runtime = L.runtime_info()
+    try:
+        runtime = L.runtime_info()
+    except Exception as exc:  # noqa: BLE001 - a diagnostics block must not be able to take the measurement with it
+        runtime = {"error": repr(exc)}
+    runtime.setdefault("devices", [])
+    runtime.setdefault("visible_devices", ndev)
     my_dev = local_rank if inproc is not None else int(os.environ.get("HVD_FORCE_DEVICE", local_rank if local_rank < ndev else local_rank % ndev))
     runtime["ranks"] = [json.loads(p_) for p_ in rdzv.allgather(json.dumps(
         {"rank": rank, "device": my_dev, "pid": os.getpid(),
