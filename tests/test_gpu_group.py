@@ -31,6 +31,12 @@ def test_group_of_three_contexts_on_one_device(gpu):
     _run("0,0,0")
 
 
+def test_group_of_eight_contexts_on_one_device(gpu):
+    """World 8 -- the size of the driver's scale run -- through every drop-in surface, against the oracle: the tile partition
+    (rb + cb) % 8, the fixed-slot candidate exchange and the key-list exchange of the video search with eight participants."""
+    _run("0,0,0,0,0,0,0,0")
+
+
 def test_group_over_rccl_when_the_node_has_more_gpus(gpu):
     n = gpu.device_count()
     if n < 2:
