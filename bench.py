@@ -202,31 +202,41 @@ def videohasher_stream_leg(lib, L, synth, vpdq):
         nt_level = C.c_int(0)
         L.check(lib.hvd_debug_get(b"copy_nt", C.byref(nt_level)))
         res["copy_nt_level"] = {0: "plain memcpy", 2: "AVX2 streaming stores", 3: "AVX-512 streaming stores"}.get(nt_level.value, "?")
-        for feed in ("bytes", "bytes_memcpy", "buffer", "acquire_only", "acquire_copy", "acquire_run"):  # (fast feeds first)
-            if feed == "bytes_memcpy":
-                if ch != 3 or nt_level.value == 0:
-                    continue
-                L.check(lib.hvd_debug_set(b"copy_nt", 0))
-            real = "bytes" if feed == "bytes_memcpy" else feed
-            if feed == "acquire_only":
-                assert run("acquire_copy", same).bytes == want_same  # warm-up: every slot position now holds that frame
-                expect = want_same
-            else:
-                assert run(real).bytes == want  # warm-up
-                expect = want
-            t_w = time.perf_counter()  # 0.2 s of untimed videos of the feed itself: after a pause or a slow leg (the GPU mostly idle)
-            while time.perf_counter() - t_w < 0.2:  # the first videos of a fast feed ran up to 40 % slower (clocks / DMA state):
-                run(real)                            # an artefact of the order of the legs, not of the feed
-            t = time.perf_counter()
-            for _ in range(n_videos):
-                got = run(real)
-                assert got.bytes == expect, f"VideoHasher({feed}) differs from the batch entry point"
-            dt = time.perf_counter() - t
-            if feed == "bytes_memcpy":
-                L.check(lib.hvd_debug_set(b"copy_nt", 1))
+        # Three interleaved rounds over the feeds, the MEDIAN round reported per feed (with the spread): one round is 12 videos
+        # = 60 ms per feed, and single rounds of this host-side pipeline scatter by +-10 % (page placement, the other legs'
+        # leftovers, clocks) -- more than the differences between the feeds.
+        feeds = [f_ for f_ in ("bytes", "bytes_memcpy", "buffer", "acquire_only", "acquire_copy", "acquire_run")
+                 if not (f_ == "bytes_memcpy" and (ch != 3 or nt_level.value == 0))]
+        rounds = {f_: [] for f_ in feeds}
+        for rnd in range(3):
+            for feed in feeds:  # (fast feeds first)
+                if feed == "bytes_memcpy":
+                    L.check(lib.hvd_debug_set(b"copy_nt", 0))
+                real = "bytes" if feed == "bytes_memcpy" else feed
+                if feed == "acquire_only":
+                    assert run("acquire_copy", same).bytes == want_same  # warm-up: every slot position now holds that frame
+                    expect = want_same
+                else:
+                    assert run(real).bytes == want  # warm-up
+                    expect = want
+                t_w = time.perf_counter()  # 0.2 s (first round; then 0.05 s) of untimed videos of the feed itself: after a pause or a slow
+                while time.perf_counter() - t_w < (0.2 if rnd == 0 else 0.05):  # leg the first videos of a fast feed ran up to 40 % slower
+                    run(real)                                                    # (clocks / DMA state): an artefact of the order of the legs
+                t = time.perf_counter()
+                for _ in range(n_videos):
+                    got = run(real)
+                    assert got.bytes == expect, f"VideoHasher({feed}) differs from the batch entry point"
+                rounds[feed].append(time.perf_counter() - t)
+                if feed == "bytes_memcpy":
+                    L.check(lib.hvd_debug_set(b"copy_nt", 1))
+        for feed in feeds:
+            dts = sorted(rounds[feed])
+            dt = dts[len(dts) // 2]
             fps = n_videos * frames_per_video / dt
             res[feed] = {"frames_per_s": sig(fps), "GBps": round(fps * fb / 1e9, 2), "h2d_frac": round(fps * fb / 1e9 / h2d, 3),
-                         "ms_per_video": round(dt / n_videos * 1e3, 3), "us_per_frame": round(dt / n_videos / frames_per_video * 1e6, 2)}
+                         "ms_per_video": round(dt / n_videos * 1e3, 3), "us_per_frame": round(dt / n_videos / frames_per_video * 1e6, 2),
+                         "rounds_us_per_frame": [round(x / n_videos / frames_per_video * 1e6, 2) for x in rounds[feed]]}
+        res["rounds"] = "3 interleaved rounds of %d videos per feed; the median round is reported, `rounds_us_per_frame` lists all three" % n_videos
         out[name] = res
     return out
 
