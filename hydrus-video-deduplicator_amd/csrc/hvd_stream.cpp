@@ -16,6 +16,8 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
 #include "copy_pool.h"
 #include "hvd_kernels.h"
 
@@ -84,9 +86,23 @@ extern "C" int hvd_debug_parallel_copy(void* dst, const void* src, size_t n, int
 }
 #endif
 
+// Library default of hvd_hasher_set_threads(h, 0): a quarter of the CPUs this process may run on, between 2 and 8 (the pool's
+// maximum). Eight threads were never slower than four on the hosts measured and up to 15 % faster where the copy competes
+// with the DMA engine for host memory (short bursts leave the memory to the engine: profiles/r05_vh_where.txt, end); a small
+// machine keeps its cores for the decoder.
+static int default_copy_threads() {
+    static const int n = [] {
+        int cpus = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) cpus = CPU_COUNT(&set);
+        return std::max(2, std::min(1 + hvd::CopyPool::kMaxHelpers, cpus / 4));
+    }();
+    return n;
+}
+
 struct hvd_hasher {
     int ctx = 0;           // the context (device of the group) this hasher was created on: every call runs there
-    int copy_threads = 4;  // threads that share one frame's copy into the ring (hvd_hasher_set_threads)
+    int copy_threads = default_copy_threads();  // threads that share one frame's copy into the ring (hvd_hasher_set_threads)
     int w = 0, h = 0, channels = 0;
     int64_t batch = 0;             // frames a slot holds
     int64_t limit = 0;             // frames after which the CURRENT batch is submitted: ramps up to `batch` (first_limit)
@@ -242,7 +258,7 @@ int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames,
             hvd_hasher* p = g_parked[k];
             if (p->ctx == hvd::api_context() && p->w == width && p->h == height && p->channels == channels && p->batch == batch_frames) {
                 g_parked.erase(g_parked.begin() + (long)k);
-                p->copy_threads = 4;
+                p->copy_threads = default_copy_threads();
                 *out = p;
                 return HVD_OK;
             }
@@ -357,7 +373,7 @@ int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame) {
  * reference hasher's worker threads. n <= 0: the library default (4). Frames below ~200 KB are copied by the caller. */
 int hvd_hasher_set_threads(hvd_hasher* hs, int n) {
     if (!hs) return hvd::api_fail(HVD_ERR_ARG, "NULL hasher");
-    hs->copy_threads = n <= 0 ? 4 : std::min(n, 1 + hvd::CopyPool::kMaxHelpers);
+    hs->copy_threads = n <= 0 ? default_copy_threads() : std::min(n, 1 + hvd::CopyPool::kMaxHelpers);
     return HVD_OK;
 }
 

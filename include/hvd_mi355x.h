@@ -154,7 +154,7 @@ int hvd_vpdq_match_videos_cross(const uint8_t* frames_q, const int64_t* offsets_
 typedef struct hvd_hasher hvd_hasher;
 int hvd_hasher_create(int width, int height, int channels, int64_t batch_frames, hvd_hasher** out);
 int hvd_hasher_push(hvd_hasher* hs, const uint8_t* frame);
-/* Host threads that share the copy of one frame inside hvd_hasher_push (the caller included; <= 0: library default 4;
+/* Host threads that share the copy of one frame inside hvd_hasher_push (the caller included; <= 0: library default = a quarter of the usable CPUs, between 2 and 8;
  * at most 8): what VideoHasher's num_threads (vpdqpy/vpdqpy.py:113) means on this path. One thread moves ~20 GB/s into
  * the pinned ring, the PCIe link behind it takes ~57. Frames below ~200 KB are copied by the caller alone. */
 int hvd_hasher_set_threads(hvd_hasher* hs, int n);
