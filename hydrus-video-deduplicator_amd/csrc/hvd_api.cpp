@@ -740,6 +740,11 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_pdq_down512_wave = value;
         return HVD_OK;
     }
+    if (strcmp(key, "pdq_down512_strip") == 0) {
+        if (value != 0 && value != 32 && value != 64) return fail(HVD_ERR_ARG, "pdq_down512_strip: 0 by batch size, 32, 64");
+        hvd::g_pdq_down512_strip = value;
+        return HVD_OK;
+    }
     if (strcmp(key, "pdq_down512_wave_grid") == 0) {
         if (value < 0) return fail(HVD_ERR_ARG, "pdq_down512_wave_grid must not be negative (0 = default)");
         hvd::g_pdq_down512_wave_grid = value;

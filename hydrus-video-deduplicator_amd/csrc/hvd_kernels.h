@@ -100,6 +100,7 @@ extern int g_pdq_dct_mode;
 extern bool g_pdq_fused_down512;
 extern int g_pdq_down512_wave;
 extern int g_pdq_down512_wave_grid;
+extern int g_pdq_down512_strip;
 hipError_t launch_pdq_hash64(const void* d_in, int kind, int64_t n, const float* d_dct, uint8_t* d_hashes,
                              int32_t* d_quality, hipStream_t s);
 

@@ -807,14 +807,18 @@ __device__ __forceinline__ void column_pass512(float* col, const int stride, flo
 // (Measured and dropped, profiles/r01_pmc_down512.txt: pass D as its own kernel -- same speed; 64-column strips with
 // one workgroup per CU -- 15 % slower; a 9-wave systolic form with LDS mailboxes -- same speed. The lever turned out
 // to be a different decomposition altogether: k_down512w below.)
-template <int CH>
-__global__ __launch_bounds__(512, 4) void k_down512(  // 2 workgroups/CU => <= 128 VGPRs
+// S = strip width. 32: 2 workgroups per CU (75.8 KB of LDS, <= 128 VGPRs), the throughput form for batches that fill the chip.
+// 64 (round 5): ONE workgroup per CU (149.5 KB), half as many strips -- and pass B, a lone wave walking 512 rows, is what a
+// frame's latency is made of, so a batch of up to 256 frames (one workgroup per CU either way: the tail batch of a streamed
+// video, a caller with a handful of frames) takes 0.12 instead of 0.19 ms (scripts/gpu_down512_small.py). At full load the wide
+// form is 15 % slower (round 1), hence the batch-size rule in launch_pdq_downsample.
+template <int CH, int S>
+__global__ __launch_bounds__(512, S == 32 ? 4 : 2) void k_down512(
     const uint8_t* __restrict__ frames, long long n, float* __restrict__ out64) {
-    constexpr int S = kS;
     constexpr int NST = kF / S;       // full strips; strip NST holds the two tail columns
     constexpr int SPS = S / 8;        // decimation samples per strip
     __shared__ float buf[kF][S + 1];
-    __shared__ float cs[4][kCsLd];
+    __shared__ float cs[SPS][kCsLd];
     const int y = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -877,7 +881,7 @@ __global__ __launch_bounds__(512, 4) void k_down512(  // 2 workgroups/CU => <= 1
             } else if (wave == 1 && k > 0) {
                 // D: samples written by C of strip k-1: slot jj <-> sample column j = 4(k-1) - 1 + jj
                 const int jj = lane, j = SPS * (k - 1) - 1 + jj;
-                if (jj < 4 && j >= 0 && j < 64) column_pass512<false>(cs[jj], 1, dst, j);
+                if (jj < SPS && j >= 0 && j < 64) column_pass512<false>(cs[jj], 1, dst, j);
             }
             __syncthreads();
 
@@ -1578,6 +1582,7 @@ size_t pdq_downsample_ws_floats(int h, int w) { return 2 * (size_t)h * w + (size
 bool g_pdq_fused_down512 = true;  // A/B switch (hvd_debug_set "pdq_fused_down512")
 int g_pdq_down512_wave = 1;       // k_down512w (one wave per frame): 0 never, 1 for batches >= 704 frames, 2 always
 int g_pdq_down512_wave_grid = 0;  // waves in flight; 0 = what is resident at once (rgb: 3 per SIMD, gray: 4)
+int g_pdq_down512_strip = 0;      // k_down512's strip width: 0 = 64 for batches of <= 256 frames, else 32; 32 / 64 forced (hvd_debug_set "pdq_down512_strip")
 
 hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int w, int channels, float* d_ws,
                                  float* d_out64, hipStream_t s) {
@@ -1599,10 +1604,19 @@ hipError_t launch_pdq_downsample(const uint8_t* d_frames, int64_t n, int h, int 
                 hipLaunchKernelGGL(k_down512w<3>, dim3(gw), dim3(64), 0, s, d_frames, (long long)n, d_out64, d_ws);
             else
                 hipLaunchKernelGGL(k_down512w<1>, dim3(gw), dim3(64), 0, s, d_frames, (long long)n, d_out64, d_ws);
-        } else if (channels == 3)
-            hipLaunchKernelGGL(k_down512<3>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
-        else
-            hipLaunchKernelGGL(k_down512<1>, dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+        } else {
+            // wide strips while every frame has a CU of its own (g_pdq_down512_strip: 0 by batch size, 32 / 64 forced)
+            const bool wide = g_pdq_down512_strip == 64 || (g_pdq_down512_strip == 0 && n <= 256);
+            const unsigned gridw = (unsigned)(n < 256 ? n : 256);
+            if (wide && channels == 3)
+                hipLaunchKernelGGL((k_down512<3, 64>), dim3(gridw), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+            else if (wide)
+                hipLaunchKernelGGL((k_down512<1, 64>), dim3(gridw), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+            else if (channels == 3)
+                hipLaunchKernelGGL((k_down512<3, kS>), dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+            else
+                hipLaunchKernelGGL((k_down512<1, kS>), dim3(grid), dim3(512), 0, s, d_frames, (long long)n, d_out64);
+        }
         return hipGetLastError();
     }
     if (jarosz_window(h) > kTW || jarosz_window(w) > kTW) return hipErrorInvalidValue;

@@ -209,6 +209,7 @@ int hvd_get_pdq_dct_mode(void);
  *   "pdq_fused_down512" 0|1                                (0: generic 4-launch down-sampler)
  *   "pdq_down512_wave" 0|1|2                               (wave-per-frame kernel: never | batches >= 704 | always)
  *   "pdq_down512_wave_grid" n                              (waves in flight; 0 = what is resident at once)
+ *   "pdq_down512_strip" 0|32|64                            (workgroup-per-frame kernel's strip width: by batch size | 32 | 64)
  *   "fp4_code", "mfma_col_chunk_max"                       (FP4-MFMA Hamming kernel)
  *   "mfma_auto_mid" 0|15..19, "mfma_auto_mid_max_x100" n   (auto variant: the pair-queue form it may pick -- 18 -- and the survivor
  *                                                           density per 1024-pair tile, x 0.01, up to which it does -- 500)

@@ -7,14 +7,15 @@ import numpy as np
 from hvd_amd import _lib as L, synth
 lib = L.init(0)
 base = synth.frames_rgb(16, seed=6)
-for n in (1, 5, 10, 21, 42, 84, 168, 336, 672):
+for n in (1, 5, 10, 21, 42, 84, 168, 256, 336, 512, 672):
     fr = np.concatenate([base] * ((n + 15) // 16))[:n]
     d_f = L.DeviceBuffer.from_array(fr)
     sb = C.c_size_t(0); L.check(lib.hvd_pdq_scratch_bytes(n, 512, 512, 3, C.byref(sb)))
     d_s = L.DeviceBuffer(sb.value); d_h = L.DeviceBuffer(32 * n); d_q = L.DeviceBuffer(4 * n)
     out = {}
-    for name, (fused, wave) in {"workgroup": (1, 0), "wave": (1, 2), "generic": (0, 1)}.items():
+    for name, (fused, wave, strip) in {"workgroup": (1, 0, 32), "wg64": (1, 0, 64), "wave": (1, 2, 0), "generic": (0, 1, 0)}.items():
         L.check(lib.hvd_debug_set(b"pdq_fused_down512", fused)); L.check(lib.hvd_debug_set(b"pdq_down512_wave", wave))
+        L.check(lib.hvd_debug_set(b"pdq_down512_strip", strip))
         ks = []
         for r in range(25):
             L.check(lib.hvd_timer_start())
@@ -22,7 +23,7 @@ for n in (1, 5, 10, 21, 42, 84, 168, 336, 672):
             ms = C.c_float(0); L.check(lib.hvd_timer_stop(C.byref(ms)))
             if r >= 5: ks.append(ms.value)
         out[name] = (float(np.mean(ks)), d_h.to_array(np.uint8, 32 * n).copy())
-    L.check(lib.hvd_debug_set(b"pdq_fused_down512", 1)); L.check(lib.hvd_debug_set(b"pdq_down512_wave", 1))
+    L.check(lib.hvd_debug_set(b"pdq_fused_down512", 1)); L.check(lib.hvd_debug_set(b"pdq_down512_wave", 1)); L.check(lib.hvd_debug_set(b"pdq_down512_strip", 0))
     same = all(np.array_equal(out["workgroup"][1], out[k][1]) for k in out)
-    print(f"n={n:4d}: workgroup {out['workgroup'][0]:.3f}  wave {out['wave'][0]:.3f}  generic {out['generic'][0]:.3f} ms   identical {same}", flush=True)
+    print(f"n={n:4d}: workgroup {out['workgroup'][0]:.3f}  wg64 {out['wg64'][0]:.3f}  wave {out['wave'][0]:.3f}  generic {out['generic'][0]:.3f} ms   identical {same}", flush=True)
     for b in (d_f, d_s, d_h, d_q): b.free()

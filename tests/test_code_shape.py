@@ -166,8 +166,10 @@ PDQ = {
     "k_pdq_hash64_fma<1>": dict(waves=3),
     "k_down512w<3>": dict(waves=3),                 # one wave per RGB frame: 12 waves per CU
     "k_down512w<1>": dict(waves=4),
-    "k_down512<3>": dict(waves=4),                  # 512 lanes x 2 workgroups per CU
-    "k_down512<1>": dict(waves=4),
+    "k_down512<3, 32>": dict(waves=4),              # 512 lanes x 2 workgroups per CU
+    "k_down512<1, 32>": dict(waves=4),
+    "k_down512<3, 64>": dict(waves=2),              # round 5: 64-column strips, ONE workgroup per CU (149.5 KB of LDS): batches <= 256 frames
+    "k_down512<1, 64>": dict(waves=2),
 }
 
 

@@ -588,6 +588,36 @@ def test_k1_down512_wave_kernel_vs_oracle(gpu, hvd, oracle, n, grid, channels):
     assert np.array_equal(h, ho), f"{int((h != ho).any(1).sum())} hash mismatches"
 
 
+@pytest.mark.parametrize("strip", [32, 64])
+@pytest.mark.parametrize("n", [1, 7, 257, 300])
+@pytest.mark.parametrize("channels", [3, 1])
+def test_k1_down512_workgroup_kernel_both_strip_widths_vs_oracle(gpu, hvd, oracle, n, strip, channels):
+    """k_down512<CH, S> (workgroup per frame): S = 32 (two workgroups per CU) and S = 64 (round 5: one per CU, half the strips, the
+    low-latency form the dispatcher takes for batches of <= 256 frames), each forced at batch sizes on both sides of that rule --
+    more frames than workgroups included (grid-stride loop: the LDS buffers are reused by the next frame) -- with hard content."""
+    lib = gpu.load()
+    base_n = min(n, 24)
+    fr = (hvd.synth.frames_rgb(base_n, seed=500 + n) if channels == 3 else hvd.synth.frames_gray(base_n, seed=600 + n, h=512, w=512))
+    if base_n >= 7:
+        rng = np.random.default_rng(n + strip)
+        fr[1] = rng.integers(0, 256, fr[1].shape, dtype=np.uint8)
+        fr[2] = (rng.integers(0, 2, fr[2].shape) * 255).astype(np.uint8)
+        fr[3] = 255
+        fr[4] = 0
+    ho, qo = oracle.hash_frames(fr, num_threads=16)
+    idx = np.arange(n) % base_n
+    try:
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_wave", 0))
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_strip", strip))
+        h, q = hvd.vpdq.hash_frames(fr[idx])
+    finally:
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_wave", 1))
+        gpu.check(lib.hvd_debug_set(b"pdq_down512_strip", 0))
+    assert np.array_equal(q, qo[idx]), f"{int((q != qo[idx]).sum())} quality mismatches"
+    assert np.array_equal(h, ho[idx]), f"{int((h != ho[idx]).any(1).sum())} hash mismatches"
+    assert lib.hvd_debug_set(b"pdq_down512_strip", 48) == gpu.HVD_ERR_ARG
+
+
 def test_k1_down512_large_batch_takes_the_wave_kernel(gpu, hvd, oracle):
     """Default dispatch at a batch size that selects k_down512w (>= 704 frames): 768 rgb24 frames = 604 MB."""
     base = hvd.synth.frames_rgb(48, seed=77)
