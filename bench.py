@@ -69,6 +69,167 @@ def host_threads() -> int:
     return max(1, n)
 
 
+def oracle_check_bands(n, rows_per_block, world=8, seed=46, n_random=32, band_rows=2048):
+    """Row bands [(begin, end), ...] (ascending, disjoint) on which the CPU oracle checks an all-pairs result over a DB too
+    large to scan whole (BASELINE configs[3], 10M hashes): `n_random` random bands of `band_rows` rows,
+    the first and the last rows, and for every rank r a band that straddles the boundary between two row blocks rb-1 | rb
+    with (rb + cb_diag) mod world == r for the column chunk holding rb's diagonal -- i.e. the first tile of a row block
+    that rank owns. The oracle scans EVERY column j > i for these rows, so each band crosses every column chunk (and with
+    it tiles of every rank)."""
+    rng = np.random.default_rng(seed)
+    starts = [0, max(0, n - band_rows)]
+    starts += [int(x) for x in rng.integers(0, max(1, n - band_rows), n_random)]
+    n_rb = max(1, (n + rows_per_block - 1) // rows_per_block)
+    for r in range(world):
+        rb = int(rng.integers(1, max(2, n_rb // world))) * world + r
+        if rb < n_rb:
+            starts.append(max(0, rb * rows_per_block - band_rows // 2))
+    bands = []
+    for a in sorted(starts):
+        b = min(n, a + band_rows)
+        if bands and a < bands[-1][1]:
+            bands[-1] = (bands[-1][0], max(bands[-1][1], b))
+        else:
+            bands.append((a, b))
+    return bands
+
+
+def oracle_hash_device_frames(L, O, d_frames_ptr, n_frames, threads, h=64, w=64, chunk=131072):
+    """Read n_frames gray frames back from HBM in chunks and PDQ-hash every one with the CPU oracle (checker of the full-size
+    configs[4] test and of bench.py's config5 gate). -> (hashes u8[n,32], quality i32[n])."""
+    ho = np.empty((n_frames, 32), dtype=np.uint8)
+    qo = np.empty(n_frames, dtype=np.int32)
+    fb = h * w
+    buf = np.empty((min(chunk, max(1, n_frames)), h, w), dtype=np.uint8)
+    for k0 in range(0, n_frames, chunk):
+        m = min(chunk, n_frames - k0)
+        L.check(L.load().hvd_memcpy_d2h(buf.ctypes.data, C.c_void_p(d_frames_ptr + k0 * fb), m * fb))
+        ho[k0:k0 + m], qo[k0:k0 + m] = O.hash_frames(buf[:m], num_threads=threads)
+    return ho, qo
+
+
+def fold_frame_pairs(pairs, video, n_videos, dtype):
+    """Host statement of the video-level reduction (vpdqpy/vpdqpy.py:49-56 for every video pair): from frame pairs
+    (i < j, frames of different videos, frames stored in video order) to one record per video pair a < b with q_hits =
+    distinct frames of a that have a match in b, t_hits = distinct frames of b that have a match in a; sorted by (a, b)."""
+    a = video[pairs["i"]].astype(np.int64)
+    b = video[pairs["j"]].astype(np.int64)
+    assert (a < b).all()  # frames are in video order and pairs inside one video were filtered
+    key = a * n_videos + b
+    n_fr = np.int64(video.size)
+    q = np.unique(key * n_fr + pairs["i"].astype(np.int64)) // n_fr
+    t = np.unique(key * n_fr + pairs["j"].astype(np.int64)) // n_fr
+    kq, cq = np.unique(q, return_counts=True)
+    kt, ct = np.unique(t, return_counts=True)
+    assert np.array_equal(kq, kt)
+    out = np.zeros(kq.size, dtype=dtype)
+    out["a"], out["b"], out["q_hits"], out["t_hits"] = kq // n_videos, kq % n_videos, cq, ct
+    return out
+
+
+MAX_SCLK_MHZ = 2400.0  # MI355X peak engine clock (MI355X_MICROARCH.md): the clock the roofline peaks are quoted at
+
+
+def gpu_sysfs(pci):
+    """Power / clock read-outs of one GPU from sysfs (amdgpu hwmon + pp_dpm_sclk), keyed by its PCI address as
+    hvd_runtime_info reports it. Best effort: whatever is not readable on this box (a container without the device's sysfs
+    node, another driver) is simply absent; `error` says why when nothing could be read."""
+    import glob
+
+    out = {}
+    base = None
+    want = (pci or "").lower()
+    for d in glob.glob("/sys/bus/pci/devices/*"):
+        name = os.path.basename(d).lower()
+        if want and (name == want or name.endswith(want) or want.endswith(name)):
+            base = d
+            break
+    if base is None:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if len(cards) == 1:  # a single-GPU box: no need to match the address
+            base = os.path.dirname(cards[0])
+    if base is None:
+        return {"error": f"no sysfs node for PCI device {pci!r}"}
+
+    def read(path):
+        try:
+            return open(path).read().strip()
+        except Exception:
+            return None
+
+    for hw in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+        for key, fname, scale in (("power_w", "power1_average", 1e-6), ("power_input_w", "power1_input", 1e-6), ("power_cap_w", "power1_cap", 1e-6),
+                                  ("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6),
+                                  ("temp_c", "temp1_input", 1e-3), ("temp_hotspot_c", "temp2_input", 1e-3)):
+            v = read(os.path.join(hw, fname))
+            if v is not None:
+                try:
+                    out[key] = round(float(v) * scale, 1)
+                except ValueError:
+                    pass
+    dpm = read(os.path.join(base, "pp_dpm_sclk"))
+    if dpm:
+        levels = [ln.strip() for ln in dpm.splitlines()]
+        out["pp_dpm_sclk"] = levels
+        cur = [ln for ln in levels if ln.endswith("*")]
+        if cur:
+            try:
+                out["dpm_sclk_mhz"] = float(cur[0].split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+            except Exception:
+                pass
+    busy = read(os.path.join(base, "gpu_busy_percent"))
+    if busy is not None:
+        out["gpu_busy_percent"] = busy
+    if not out:
+        out["error"] = f"nothing readable under {base}"
+    return out
+
+
+class PowerSampler:
+    """Background reader of gpu_sysfs() while a leg runs (the sustained leg: the headline's timed steps stay undisturbed)."""
+
+    def __init__(self, pci, period=0.05):
+        import threading
+
+        self.pci, self.period, self.samples = pci, period, []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            s_ = gpu_sysfs(self.pci)
+            if "error" not in s_:
+                self.samples.append({k: s_[k] for k in ("power_w", "power_input_w", "sclk_mhz", "dpm_sclk_mhz", "temp_hotspot_c") if k in s_})
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(2.0)
+
+    def summary(self):
+        if not self.samples:
+            return {"samples": 0}
+        out = {"samples": len(self.samples)}
+        for k in self.samples[0]:
+            xs = [s_[k] for s_ in self.samples if k in s_]
+            if xs:
+                out[k] = {"mean": round(float(np.mean(xs)), 1), "min": min(xs), "max": max(xs)}
+        return out
+
+
+def pass_clock_mhz(lib, L):
+    """Effective shader clock (MHz) of this context's FP4-MFMA all-pairs passes since the last reset (in-kernel s_memtime /
+    s_memrealtime brackets of one workgroup in eight: include/hvd_mi355x.h "mfma_pass_khz"), and the number of samples."""
+    khz, ns = C.c_int(0), C.c_int(0)
+    L.check(lib.hvd_debug_get(b"mfma_pass_khz", C.byref(khz)))
+    L.check(lib.hvd_debug_get(b"mfma_clock_samples", C.byref(ns)))
+    return (khz.value / 1e3 if khz.value > 0 else None), ns.value
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +241,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=-1, help="all-pairs kernel variant (-1: product default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--oracle-check-seconds", type=float, default=90.0,
+                    help="budget (estimated CPU seconds) of EACH full-size oracle gate of the cpu_baseline leg (config4 row bands, "
+                         "config5 every frame + every frame pair); a gate whose estimate exceeds it is skipped with the reason")
     ap.add_argument("--sustain-seconds", type=float, default=12.0, help="length of the sustained leg at N=1 (0: skip)")
     ap.add_argument("--no-extras", action="store_true", help="headline + frames_hashed only")
     ap.add_argument("--cfg5-videos", type=int, default=50_000)
@@ -427,6 +591,8 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         rdzv.barrier()
 
     variant = search.DEFAULT_VARIANT if args.variant < 0 else args.variant
+    # the semantics the absent wheel leaves open: every artefact carries the labels
+    policies = hvd_amd.vpdq.policy_labels()
     # what the ranks run on: versions, library paths, every rank's device, the peer links between them (xGMI or PCIe)
     try:
         runtime = L.runtime_info()
@@ -435,9 +601,10 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
     runtime.setdefault("devices", [])
     runtime.setdefault("visible_devices", ndev)
     my_dev = local_rank if inproc is not None else int(os.environ.get("HVD_FORCE_DEVICE", local_rank if local_rank < ndev else local_rank % ndev))
+    my_pci = next((d_["pci"] for d_ in runtime["devices"] if d_["index"] == my_dev), "?")
     runtime["ranks"] = [json.loads(p_) for p_ in rdzv.allgather(json.dumps(
         {"rank": rank, "device": my_dev, "pid": os.getpid(),
-         "pci": next((d_["pci"] for d_ in runtime["devices"] if d_["index"] == my_dev), "?"),
+         "pci": my_pci,
          "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))}).encode())]
     links = sorted({p_["link"] for p_ in runtime.get("peers", [])})
     runtime["xgmi_or_pcie"] = "/".join(links) if links else ("single device" if runtime["visible_devices"] <= 1 else "?")
@@ -518,12 +685,17 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
 
         for _ in range(warmup):
             step(timed=False)
+        if v >= 8:
+            L.check(lib.hvd_debug_set(b"mfma_clock_reset", 1))  # (enqueued in stream order; read after the timed region)
+        sys_before = gpu_sysfs(my_pci)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             recs = step()
         barrier()
         elapsed = rdzv.allreduce_max([time.perf_counter() - t0])[0]
+        sys_after = gpu_sysfs(my_pci)
+        clk_mhz, clk_samples = pass_clock_mhz(lib, L) if v >= 8 else (None, 0)
         merged = M.merge_pairs([recs])
         if verify:
             # parity gate that runs with every measurement: every reported pair verifies on the host with its exact
@@ -538,6 +710,8 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         digest = int(np.bitwise_xor.reduce(merged.view(np.uint32).astype(np.uint64) *
                                            np.arange(1, merged.size * 4 + 1, dtype=np.uint64))) if merged.size else 0
         per_rank = rdzv.allgather(json.dumps({"rank": rank, "kernel_ms": round(float(np.mean(kms)), 3),
+                                              "effective_mhz": round(clk_mhz, 1) if clk_mhz else None, "clock_samples": clk_samples,
+                                              "sysfs_before": sys_before, "sysfs_after": sys_after,
                                               **{k_: round(float(np.mean(v_)), 3) for k_, v_ in split.items() if k_ != "kernel_ms"},
                                               "pairs": my_pairs[0], "merged_pairs": int(merged.size), "digest": digest,
                                               "steps": split}).encode())
@@ -621,6 +795,9 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
     # with the reason in place of the leg, and the process leaves with os._exit (a rank stuck in a collective cannot be
     # joined).
     extras = {}
+    # the full-size oracle gates of the cpu_baseline leg (below) need what these legs produced: kept on the host / in HBM until then
+    want_oracle_gates = world == 1 and not args.no_cpu_baseline and not args.no_extras
+    keep_for_gates = {}
 
     def run_extras():
         if not args.no_extras:
@@ -631,6 +808,8 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                 r4 = allpairs_workload(n4, 4, steps=1, warmup=0)
                 for b in r4["bufs"]:
                     b.free()
+                if want_oracle_gates:
+                    keep_for_gates["cfg4"] = (r4["db"], r4["merged"])
                 extras["cfg4"] = {"workload": "BASELINE configs[3]: one all-pairs pass over 10M synthetic hashes (4.9999995e13 comparisons), "
                                     f"sharded tile-cyclically over {world} GPU(s), candidates all-gathered ({exchange_kind})",
                         "value": sig(n4 * (n4 - 1) / 2 / r4["elapsed"], 5), "unit": "comparisons/s", "n_gpus": world,
@@ -673,6 +852,9 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                 stage5.append(rdzv.allreduce_max([tm5[k_] for k_ in STAGES5]))
                 mine5 = {k_: round(tm5[k_], 3) for k_ in STAGES5}
                 kept5, lens5 = lib5.n_frames, lib5.lengths()
+                if want_oracle_gates and len(times) == 3:  # (after the last pass's clock has stopped)
+                    keep_for_gates["cfg5"] = {"hashes": lib5.hashes(), "offsets": lib5.offsets(), "recs": recs5, "V": V, "F": F,
+                                              "d_frames": d_frames, "video": lib5.d_video.to_array(np.int32, lib5.n_frames)}
                 lib5.free()
             fv5 = C.c_int(0)
             L.check(lib.hvd_debug_get(b"mfma_auto_form", C.byref(fv5)))
@@ -681,7 +863,8 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                 pv_ = C.c_int(0)
                 L.check(lib.hvd_debug_get(key_.encode(), C.byref(pv_)))
                 probe5[key_] = pv_.value
-            d_frames.free()
+            if "cfg5" not in keep_for_gates:
+                d_frames.free()
             d_copy.free()
             planted5 = {(int(min(s, d)), int(max(s, d))) for d, s in enumerate(copy_of) if s >= 0}
             found5 = {tuple(p) for p in pairs5.tolist()}
@@ -701,7 +884,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             exec_cmp5 = float(kept5) * (float(kept5) - 1.0) / 2.0 / world
             flop5 = exec_cmp5 / 1024.0 * 2.0 * 131072.0
             search5 = {"ms": round(search5_ms, 3), "ms_sd": round(search5_sd, 3), "form": int(fv5.value),
-                       "form_name": {9: "fetch", 12: "register cascade", 15: "pair queue (group masks)", 18: "pair queue (panel marks)"}.get(int(fv5.value), "?"),
+                       "form_name": {9: "fetch", 12: "register cascade", 18: "pair queue (panel marks)"}.get(int(fv5.value), "?"),
                        "first_stage": {"bit_order_chosen_from_the_library": bool(probe5["vmatch_bit_order_used"]),
                                        "selection": {0: "bits 0..127", 1: "bits 128..255", 2: "bits 0..63 + 192..255"}.get(probe5["mfma_auto_half"], "?")
                                                     + (" of the rewritten hashes" if probe5["vmatch_bit_order_used"] else ""),
@@ -737,8 +920,8 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                     "per_rank": per_rank5,
                     "video_records": int(len(recs5)), "duplicate_pairs": int(len(pairs5)),
                     "planted_copies": len(planted5), "planted_recall": round(len(planted5 & found5) / max(1, len(planted5)), 4),
-                    "gate": "identical record checksum on every rank; tests/test_gpu_round2.py checks the same pipeline against "
-                            "the oracle (hashes of 10k frames, records of a 3000-video sub-library)"}
+                    "gate": "identical record checksum on every rank; at N=1 the cpu_baseline leg puts the oracle behind the WHOLE "
+                            "config (full_size_oracle_check: every frame's hash, every record); tests/test_gpu_round5.py does the same"}
 
     extras_note = None
     if world == 1:
@@ -798,7 +981,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                          "because tiles re-use operands from registers/LDS"}
     if variant >= 8:
         # executed matrix work: 2 (128-bit first stage) or 4 MFMAs of 2*32*32*64 flop per 1024 comparisons
-        flop_per_cmp = 256.0 if form in (9, 11, 12, 15, 18) else 512.0
+        flop_per_cmp = 256.0 if form in (9, 12, 18) else 512.0
         tfl = cmp_per_launch * flop_per_cmp / (kernel_avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": f"k_allpairs_mfma(variant={variant}" + (f" -> form {form} chosen by the probe)" if variant == 13 else ")"),
                     "achieved": round(tfl, 1),
@@ -809,6 +992,17 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                     "flop_per_comparison_executed": flop_per_cmp, "hbm_equivalent": hbm_equiv,
                     "note": "kernel_ms covers everything between the HIP events of one pass: probe + form selection + the "
                             "all-pairs kernel; `achieved` counts only the first-stage MFMAs every comparison executes"}
+        # the clock the timed passes actually ran at (in-kernel s_memtime / s_memrealtime, slowest rank) and the roofline against
+        # the peak AT THAT CLOCK: tells a slow box (power-limited clock) from a slow kernel
+        slow = max(head["per_rank"], key=lambda p_: p_["kernel_ms"])
+        if slow.get("effective_mhz"):
+            roofline["effective_mhz"] = slow["effective_mhz"]
+            roofline["clock_samples"] = slow["clock_samples"]
+            roofline["peak_at_clock"] = round(FP4_PEAK_TFLOPS * slow["effective_mhz"] / MAX_SCLK_MHZ, 1)
+            roofline["frac_at_clock"] = round(tfl / (FP4_PEAK_TFLOPS * slow["effective_mhz"] / MAX_SCLK_MHZ), 3)
+            roofline["clock_note"] = (f"peak quoted at {MAX_SCLK_MHZ:.0f} MHz; effective_mhz = shader cycles / constant-rate ticks of one "
+                                      "workgroup in eight of the timed passes (k_allpairs_mfma); frac_at_clock = achieved / (peak x "
+                                      "effective_mhz / 2400): pipe utilisation at the clock the power limit allowed")
     else:
         roofline = {"bound": "hbm", "kernel": f"k_allpairs(variant={variant})", "traffic": traffic,
                     "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
@@ -903,7 +1097,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         # every exact form next to the default, for transparency (same DB, same launch shape)
         for v, name in ((0, "popcount_full_16op"), (1, "popcount_prefilter128"), (8, "mfma_fp4_full_256"),
                         (9, "mfma_fp4_stage128_fetch"), (12, "mfma_fp4_stage128_registers"),
-                        (15, "mfma_fp4_stage128_pair_queue"), (18, "mfma_fp4_stage128_panel_mark_queue")):
+                        (18, "mfma_fp4_stage128_panel_mark_queue")):
             mu, sd, _ = time_variant(v, reps=3)
             extra[name] = {"kernel_ms": round(mu, 3), "kernel_ms_sd": round(sd, 3), "comparisons_per_s": sig(total_cmp / (mu * 1e-3))}
         out["kernel_variants"] = extra
@@ -981,17 +1175,23 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         if args.sustain_seconds > 0:
             reps = max(10, int(args.sustain_seconds / (k_mean * 1e-3)))
             d_cnt.zero()
-            L.check(lib.hvd_timer_start())
-            for _ in range(reps):
-                if variant >= 8:
-                    L.check(lib.hvd_dev_expand_fp4(d_db.ptr, n, d_img.ptr))
-                M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n, None, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, variant)
-            ms = C.c_float(0)
-            L.check(lib.hvd_timer_stop(C.byref(ms)))
+            if variant >= 8:
+                L.check(lib.hvd_debug_set(b"mfma_clock_reset", 1))
+            with PowerSampler(my_pci) as ps:  # power / clock read-outs every 50 ms while the passes run (host thread, sysfs)
+                L.check(lib.hvd_timer_start())
+                for _ in range(reps):
+                    if variant >= 8:
+                        L.check(lib.hvd_dev_expand_fp4(d_db.ptr, n, d_img.ptr))
+                    M.launch_allpairs(lib, d_db.ptr, d_img.ptr, n, None, 31, 0, 1, d_pairs.ptr, cap, d_cnt.ptr, variant)
+                ms = C.c_float(0)
+                L.check(lib.hvd_timer_stop(C.byref(ms)))
             assert int(d_cnt.to_array(np.uint64, 1)[0]) == reps * len(merged)
+            s_mhz, s_n = pass_clock_mhz(lib, L) if variant >= 8 else (None, 0)
             out["sustained"] = {"what": f"{reps} passes (FP4 image + all-pairs) enqueued back to back, one synchronisation at the end",
                                 "seconds": round(ms.value / 1e3, 2), "ms_per_pass": round(ms.value / reps, 3),
-                                "comparisons_per_s": sig(total_cmp / (ms.value / reps * 1e-3))}
+                                "comparisons_per_s": sig(total_cmp / (ms.value / reps * 1e-3)),
+                                "effective_mhz": round(s_mhz, 1) if s_mhz else None, "clock_samples": s_n,
+                                "sysfs_during": ps.summary()}
         for b in (d_db, d_img, d_pairs, d_cnt):
             b.free()
 
@@ -1100,6 +1300,63 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
                    "note": "the reference's real CPU path (hvdaccelerators 0.4.0) is not installable offline; this "
                            "is the oracle port"}
 
+            # ---- full-size oracle gates: the two BASELINE configs no sampled check had behind them ----
+            # config4 (10M hashes): the oracle scans EVERY column for the rows of 40+ bands (random, first, last, one per rank
+            # straddling a row-block boundary); the GPU list restricted to those rows must be the oracle's, record for record.
+            if "cfg4" in keep_for_gates and cfg4 is not None:
+                db4, merged4 = keep_for_gates.pop("cfg4")
+                n4_ = db4.shape[0]
+                bands4 = oracle_check_bands(n4_, M.tile_geometry(n4_, 9)[0], 8, seed=46)
+                est = sum((b_ - a_) * (n4_ - (a_ + b_) / 2.0) for a_, b_ in bands4) / cpu_cmp + 2.0
+                if est > args.oracle_check_seconds:
+                    cfg4["oracle_band_check"] = None
+                    cfg4["oracle_band_check_note"] = f"skipped: estimated {est:.0f} s of CPU work > --oracle-check-seconds {args.oracle_check_seconds:.0f}"
+                else:
+                    t_ = time.perf_counter()
+                    want4 = O.allpairs_bands(db4, bands4, 31, num_threads=cores)
+                    in_band = np.zeros(n4_, dtype=bool)
+                    for a_, b_ in bands4:
+                        in_band[a_:b_] = True
+                    got4 = merged4[in_band[merged4["i"]]]
+                    assert len(got4) == len(want4) and all(np.array_equal(got4[f_], want4[f_]) for f_ in ("i", "j", "dist")), \
+                        f"config4: GPU pair list differs from the oracle on the sampled row bands ({len(got4)} vs {len(want4)} records)"
+                    cfg4["oracle_band_check"] = True
+                    cfg4["oracle_band_check_note"] = (f"{len(bands4)} row bands ({sum(b_ - a_ for a_, b_ in bands4)} rows x every column j > i of the "
+                                                      f"{n4_} hashes), {len(want4)} records equal, {time.perf_counter() - t_:.1f} s on {cores} threads")
+                del db4, merged4
+            # config5 (50k videos x 64 frames): every frame hashed by the oracle -> kept hashes and CSR byte-equal to the device
+            # library's; the oracle's scan over all kept x kept frame pairs with the video group filter, folded on the host to
+            # video-level counters, equal to the product's hvd_vmatch records.
+            if "cfg5" in keep_for_gates and cfg5 is not None:
+                k5 = keep_for_gates.pop("cfg5")
+                nfr5, kept5_ = k5["V"] * k5["F"], k5["hashes"].shape[0]
+                est = nfr5 / (nf_cpu / dtf) + kept5_ * (kept5_ - 1) / 2.0 / cpu_cmp + 3.0
+                if est > args.oracle_check_seconds:
+                    cfg5["full_size_oracle_check"] = None
+                    cfg5["full_size_oracle_check_note"] = f"skipped: estimated {est:.0f} s of CPU work > --oracle-check-seconds {args.oracle_check_seconds:.0f}"
+                else:
+                    t_ = time.perf_counter()
+                    ho5, qo5 = oracle_hash_device_frames(L, O, k5["d_frames"].ptr, nfr5, cores)
+                    t_h = time.perf_counter() - t_
+                    keep5 = qo5 >= 31
+                    off5 = np.zeros(k5["V"] + 1, dtype=np.int64)
+                    np.cumsum(keep5.reshape(k5["V"], k5["F"]).sum(1), out=off5[1:])
+                    kept_o5 = np.ascontiguousarray(ho5[keep5])
+                    assert np.array_equal(k5["offsets"], off5), "config5: per-video CSR of the kept frames differs from the oracle's"
+                    assert np.array_equal(k5["hashes"], kept_o5), "config5: kept frame hashes differ from the oracle's"
+                    fp5 = O.allpairs(kept_o5, 31, group=k5["video"], cap=1 << 22, num_threads=cores)
+                    want5 = fold_frame_pairs(fp5, k5["video"], k5["V"], L.VMATCH_DTYPE)
+                    assert np.array_equal(k5["recs"], want5), \
+                        f"config5: video records differ from the fold of the oracle's frame pairs ({len(k5['recs'])} vs {len(want5)})"
+                    cfg5["full_size_oracle_check"] = True
+                    cfg5["full_size_oracle_check_note"] = (f"oracle hashed all {nfr5} frames ({t_h:.1f} s): {kept5_} kept hashes + CSR byte-equal; "
+                                                           f"oracle scan of {kept5_ * (kept5_ - 1) / 2.0:.4g} frame pairs with the video filter -> "
+                                                           f"{len(fp5)} frame pairs -> {len(want5)} video records equal; "
+                                                           f"{time.perf_counter() - t_:.1f} s on {cores} threads")
+                    cfg5["cpu_frames_per_s_full_library"] = sig(nfr5 / t_h)
+                k5["d_frames"].free()
+                del k5
+
         # the reference-shaped loop -- one Python call per video pair, as db/vptree.py:29-31,737 issues them
         # (tests/benchmarks/test_benchmark_vpdqpy.py:62-73 has the same shape). 64-frame hashes, 1024 calls.
         vf, voff, _ = synth.video_hashes(33, seed=1, frames_per_video=64, copy_fraction=0.1)
@@ -1165,7 +1422,17 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
         conn.close()
 
     out["frames_hashed"] = frames_out
+    for pr in head["per_rank"]:  # clock / power of the timed region, per device
+        rk = next((r_ for r_ in runtime.get("ranks", []) if r_.get("rank") == pr["rank"]), None)
+        dev = next((d_ for d_ in runtime.get("devices", []) if rk and d_.get("pci") == rk.get("pci")), None)
+        tel = {"rank": pr["rank"], "effective_mhz_timed_passes": pr.get("effective_mhz"), "clock_samples": pr.get("clock_samples"),
+               "sysfs_before_timed_region": pr.get("sysfs_before"), "sysfs_after_timed_region": pr.get("sysfs_after")}
+        if dev is not None:
+            dev.setdefault("telemetry", []).append(tel)
+        else:
+            runtime.setdefault("telemetry_unmatched", []).append(tel)
     out["runtime"] = runtime
+    out["policies"] = policies
     if cpu:
         out["cpu_baseline"] = cpu
         out["full_size_oracle_check"] = cpu["full_size_oracle_check"]

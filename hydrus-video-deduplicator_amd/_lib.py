@@ -204,7 +204,11 @@ def runtime_info() -> dict:
 
     buf = C.create_string_buffer(1 << 16)
     check(load().hvd_runtime_info(buf, len(buf)))
-    return json.loads(buf.value.decode("utf-8", "replace"))
+    info = json.loads(buf.value.decode("utf-8", "replace"))
+    from . import vpdq  # (the comparator / reduction policies live above the C-ABI, which takes an inclusive distance bound)
+
+    info["policies"] = vpdq.policy_labels()
+    return info
 
 
 def ensure() -> C.CDLL:

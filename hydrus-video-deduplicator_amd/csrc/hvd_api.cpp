@@ -712,7 +712,7 @@ int hvd_debug_set(const char* key, int value) {
         return HVD_OK;
     }
     if (strcmp(key, "mfma_auto_mid") == 0) {  // form the auto variant runs on data with common false survivors
-        if (value != 0 && (value < 15 || value > 19)) return fail(HVD_ERR_ARG, "mfma_auto_mid: 15 .. 19 (pair-queue forms) or 0 (none: fetch or register form only)");
+        if (value != 0 && value != 18) return fail(HVD_ERR_ARG, "mfma_auto_mid: 18 (panel-mark queue form) or 0 (none: fetch or register form only)");
         hvd::g_mfma_auto_mid = (uint32_t)value;
         return HVD_OK;
     }
@@ -756,7 +756,8 @@ int hvd_debug_set(const char* key, int value) {
         return HVD_OK;
     }
     if (strcmp(key, "vmatch_variant") == 0) {  // tests / scripts/gpu_fuzz_k3.py: the video-level searches through one explicit form
-        if (value != 0 && (value < 8 || value > 19)) return fail(HVD_ERR_ARG, "vmatch_variant: 0 (default) or an MFMA form 8..19");
+        if (value != 0 && value != 8 && value != 9 && value != 12 && value != 13 && value != 18)
+            return fail(HVD_ERR_ARG, "vmatch_variant: 0 (default) or an MFMA form: 8, 9, 12, 13 (auto), 18");
         // every context of the group: forms differ in their tile height, so ranks on different forms would walk different
         // (rb + cb) % world partitions -- tiles skipped or compared twice
         for (int k = 0; k < g_nctx; ++k) g_ctx[k].v_variant = value;
@@ -788,6 +789,11 @@ int hvd_debug_set(const char* key, int value) {
     }
     if (strcmp(key, "copy_nt") == 0) {  // hvd_hasher_push: non-temporal stores into the pinned ring (1, default where the CPU has them) or plain memcpy (0)
         hvd::stream_set_copy_nt(value);
+        return HVD_OK;
+    }
+    if (strcmp(key, "mfma_clock_reset") == 0) {  // telemetry: clear this context's clock accumulators (in stream order)
+        if (int rc = need_ready()) return rc;
+        HIP_TRY(hvd::mfma_clock_reset(t_ctx, g.stream));
         return HVD_OK;
     }
     return fail(HVD_ERR_ARG, "unknown debug key %s", key);
@@ -839,16 +845,20 @@ int hvd_debug_get(const char* key, int* out_value) {
                 return HVD_OK;
             }
     }
-    if (strncmp(key, "mfma_qstat", 10) == 0 && key[10] >= '0' && key[10] <= '9') {  // HVD_K2_QSTATS builds (dev tool); reading clears
-        const int k = atoi(key + 10);
-        if (k < 0 || k > 15) return fail(HVD_ERR_ARG, "mfma_qstat0..15");
-        uint32_t* sel = nullptr;
-        HIP_TRY(hvd::mfma_select_buffer(t_ctx, &sel));
-        unsigned long long v = 0;
-        HIP_TRY(hipMemcpyAsync(&v, sel + 128 + 2 * k, 8, hipMemcpyDeviceToHost, g.stream));
-        HIP_TRY(hipMemsetAsync(sel + 128 + 2 * k, 0, 8, g.stream));
-        HIP_TRY(hipStreamSynchronize(g.stream));
-        *out_value = (int)(v > 0x7FFFFFFFull ? 0x7FFFFFFF : v);
+    if (strcmp(key, "mfma_pass_khz") == 0 || strcmp(key, "mfma_clock_samples") == 0) {
+        // telemetry (round 6): the shader clock the FP4-MFMA all-pairs passes of this context actually ran at since the last
+        // "mfma_clock_reset" -- sampled workgroups' s_memtime cycles over their s_memrealtime ticks (k_allpairs_mfma) x the
+        // tick rate the runtime reports (hipDeviceAttributeWallClockRate, kHz); waits for the stream. 0: nothing sampled.
+        unsigned long long v[4] = {0, 0, 0, 0};
+        HIP_TRY(hvd::mfma_clock_read(t_ctx, g.stream, v));
+        if (key[5] == 'c') {
+            *out_value = (int)std::min<unsigned long long>(v[2], 0x7FFFFFFFull);
+            return HVD_OK;
+        }
+        int dev = 0, wall_khz = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev));
+        *out_value = v[1] ? (int)((double)v[0] / (double)v[1] * (double)wall_khz + 0.5) : 0;
         return HVD_OK;
     }
     return fail(HVD_ERR_ARG, "unknown debug key %s", key);
@@ -940,6 +950,8 @@ int hvd_dev_allpairs_hamming256_mfma(const void* d_db, const void* d_img, int64_
     if (cap < 0 || !d_count || (cap > 0 && !d_pairs)) return fail(HVD_ERR_ARG, "bad output buffer");
     if (n < 2) return HVD_OK;
     if (!d_img || !d_db) return fail(HVD_ERR_ARG, "d_db / d_img is NULL");
+    if (variant != 8 && variant != 9 && variant != 12 && variant != 13 && variant != 18)
+        return fail(HVD_ERR_ARG, "unknown FP4-MFMA variant %d (8, 9, 12, 18, or 13 = chosen by the probe)", variant);
     hvd::AllPairsArgs a;
     a.d_db = d_db;
     a.n = (uint32_t)n;
@@ -967,6 +979,7 @@ int hvd_dev_allpairs_hamming256(const void* d_db, int64_t n, const void* d_group
     if (cap < 0 || !d_count || (cap > 0 && !d_pairs)) return fail(HVD_ERR_ARG, "bad output buffer");
     if (n < 2) return HVD_OK;
     if (!d_db) return fail(HVD_ERR_ARG, "d_db is NULL");
+    if (variant != 0 && variant != 1) return fail(HVD_ERR_ARG, "unknown popcount variant %d (0 | 1)", variant);
     hvd::AllPairsArgs a;
     a.d_db = d_db;
     a.n = (uint32_t)n;

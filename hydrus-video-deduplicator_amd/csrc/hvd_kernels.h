@@ -33,7 +33,7 @@ struct AllPairsArgs {
 hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s);
 bool allpairs_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32_t* col_chunk);
 
-// FP4-MFMA form (k_hamming_mfma.hip), variants 8..11. d_img: fp4_rows_padded(n)*128 bytes.
+// FP4-MFMA forms (k_hamming_mfma.hip), variants 8, 9, 12, 13 (auto), 18. d_img: fp4_rows_padded(n)*128 bytes.
 uint32_t fp4_rows_padded(uint32_t n);
 extern uint32_t g_mfma_col_chunk_max;
 extern uint32_t g_mfma_auto_mid, g_mfma_auto_mid_max_x100, g_mfma_queue_packed, g_mfma_lds_pad;
@@ -50,6 +50,9 @@ hipError_t launch_allpairs_mfma(const AllPairsArgs& a, const void* d_img, hipStr
 hipError_t launch_cross_mfma(const AllPairsArgs& a, const void* d_img_q, uint32_t nq, const void* d_img_t,
                              const int32_t* d_group_t, hipStream_t s);
 hipError_t mfma_select_buffer(int ctx_id, uint32_t** out);  // per context; [0] = form the auto variant ran last, [1] = probe survivors
+// clock telemetry of a context's all-pairs passes: {shader cycles, constant-rate ticks, sampled workgroups, 0} since the reset
+hipError_t mfma_clock_reset(int ctx_id, hipStream_t s);
+hipError_t mfma_clock_read(int ctx_id, hipStream_t s, unsigned long long out[4]);
 void mfma_release();
 void pdq_release();           // k_pdq.hip: free the hash kernel's work-counter ring (hvd_shutdown)
 void stream_release_cache();  // hvd_stream.cpp: free the parked hasher slot sets (hvd_shutdown)

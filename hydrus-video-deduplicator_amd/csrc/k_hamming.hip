@@ -402,9 +402,7 @@ static hipError_t launch_allpairs_t(const AllPairsArgs& a, hipStream_t s) {
 
 static int variant_rows(int variant) {
     switch (variant) {
-        case 0: case 1: case 5: case 6: return 4;
-        case 2: case 3: return 8;
-        case 4: return 2;
+        case 0: case 1: return 4;
         default: return 0;
     }
 }
@@ -427,11 +425,6 @@ hipError_t launch_allpairs(const AllPairsArgs& a, hipStream_t s) {
     switch (a.variant) {
         case 0: return launch_allpairs_t<4, 4, false>(a, s);
         case 1: return launch_allpairs_t<4, 4, true>(a, s);
-        case 2: return launch_allpairs_t<8, 2, false>(a, s);
-        case 3: return launch_allpairs_t<8, 2, true>(a, s);
-        case 4: return launch_allpairs_t<2, 8, false>(a, s);
-        case 5: return launch_allpairs_t<4, 2, false>(a, s);
-        case 6: return launch_allpairs_t<4, 8, false>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -29,12 +29,6 @@
 #include <stdint.h>
 #include <string.h>
 
-// HVD_K2_QABL=<n> builds are timing-only ABLATIONS that produce WRONG RESULTS (survivors counted but not pushed, entries
-// dropped, ...); HVD_K2_QSTATS adds counters to the hot loop. Neither may come out of the product source with a single -D:
-#if (defined(HVD_K2_QABL) || defined(HVD_K2_QSTATS)) && !defined(HVD_DEV_ABLATION)
-#error "HVD_K2_QABL / HVD_K2_QSTATS are developer ablation builds (wrong results): add -DHVD_DEV_ABLATION to confirm"
-#endif
-
 #include <mutex>
 
 #include "hvd_devhash.h"
@@ -200,23 +194,6 @@ __device__ __forceinline__ int or16_bits(const v16f& c) {
     return m0 | m3;
 }
 
-// The same tree, keeping its six first-level results: group g < 5 = registers 3g..3g+2, group 5 = register 15. The pair-queue
-// form tells WHICH registers of a lane hold a survivor from these (6 sign bits) instead of from the 16 accumulators.
-struct Or16Groups {
-    int g[6];
-    int all;
-};
-__device__ __forceinline__ Or16Groups or16_groups(const v16f& c) {
-    Or16Groups o;
-    o.g[0] = __float_as_int(c[0]) | __float_as_int(c[1]) | __float_as_int(c[2]);
-    o.g[1] = __float_as_int(c[3]) | __float_as_int(c[4]) | __float_as_int(c[5]);
-    o.g[2] = __float_as_int(c[6]) | __float_as_int(c[7]) | __float_as_int(c[8]);
-    o.g[3] = __float_as_int(c[9]) | __float_as_int(c[10]) | __float_as_int(c[11]);
-    o.g[4] = __float_as_int(c[12]) | __float_as_int(c[13]) | __float_as_int(c[14]);
-    o.g[5] = __float_as_int(c[15]);
-    o.all = (o.g[0] | o.g[1] | o.g[2]) | (o.g[3] | o.g[4] | o.g[5]);
-    return o;
-}
 
 __device__ __forceinline__ float min16(const v16f& c) {
     float m0 = fminf(fminf(c[0], c[1]), c[2]);
@@ -252,6 +229,7 @@ __device__ __forceinline__ void append_pair_m(hvd_pair* out, unsigned long long 
 constexpr uint32_t kWgPairs = 512;
 __shared__ hvd_pair g_wg_pairs[kWgPairs];
 __shared__ uint32_t g_wg_npairs;
+__shared__ unsigned long long g_clk_t0[2];  // clock telemetry: a sampled workgroup's start values (see the kernel)
 
 __device__ __forceinline__ void append_pair_wg(hvd_pair* out, unsigned long long cap, unsigned long long* count,
                                                uint32_t i, uint32_t j, uint32_t dist) {
@@ -267,15 +245,6 @@ __device__ __forceinline__ void append_pair_wg(hvd_pair* out, unsigned long long
         append_pair_m(out, cap, count, i, j, dist);
     }
 }
-
-#ifndef HVD_K2_SIGN
-#define HVD_K2_SIGN 1  // 1: threshold folded into negated accumulators, OR-reduction (or16_bits); 0: plain dot, max-reduction
-#endif
-constexpr bool kSign = HVD_K2_SIGN != 0;
-#ifndef HVD_K2_CASCADE
-#define HVD_K2_CASCADE 1  // 1: survivors of the 128-bit stage go 128 -> 192 -> 256; 0: 128 -> 256 (round 2)
-#endif
-constexpr bool kCascade = HVD_K2_CASCADE != 0;
 
 constexpr int kSuper = 128;  // candidates per LDS super-panel (256: -4 % with the prefilter, +2 % without)
 
@@ -306,7 +275,7 @@ struct HitCtx {
     const uint4* db_q;  // the same hashes packed (32 B each), nullable: the drain's cheaper source (2 loads per hash instead of 8)
     const uint4* db_t;
     uint32_t max_dist;
-    unsigned long long* qstats;  // HVD_K2_QSTATS builds only: counters of the pair queue's routes (dev tool)
+    unsigned long long* clk;  // clock telemetry: {shader cycles, constant-rate ticks, sampled workgroups} accumulated over passes
 };
 
 // Hits of one 32x32 tile whose accumulators hold the full 256-bit dot products: acc[r] belongs to
@@ -350,9 +319,14 @@ __device__ __forceinline__ HitCtx load_ctx(const HitCtx* ctx) {
 // (tid is an argument: a callee that reads threadIdx makes the caller keep the packed work-item ids alive in v31.)
 __device__ __noinline__ void flush_pairs_wg(const HitCtx* __restrict__ ctx, uint32_t tid, uint32_t nthreads) {
     __shared__ unsigned long long base_s;
+    const HitCtx c = load_ctx(ctx);
+    if (tid == 0u && g_clk_t0[0] != 0ull) {  // clock telemetry of a sampled workgroup (see the kernel): its lifetime ends here
+        atomicAdd(&c.clk[0], (unsigned long long)__builtin_readcyclecounter() - g_clk_t0[0]);
+        atomicAdd(&c.clk[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - g_clk_t0[1]);
+        atomicAdd(&c.clk[2], 1ull);
+    }
     const uint32_t m = min(g_wg_npairs, kWgPairs);
     if (m == 0u) return;  // uniform over the workgroup
-    const HitCtx c = load_ctx(ctx);
     if (tid == 0u) base_s = atomicAdd(c.count, (unsigned long long)m);
     __syncthreads();
     const unsigned long long base = base_s;
@@ -453,31 +427,28 @@ __device__ __noinline__ void panel_survivors(uint32_t marks, const uint4* __rest
 }
 
 
-// ---- pair queue (round 4): what a false first-stage survivor costs -------------------------------------------------
-// On real frame hashes 2.3e-4 of all pairs pass the 128-bit first stage (0.24 per 1024-pair tile) although only ~1e-8 are
+// ---- panel-mark queue: what a false first-stage survivor costs -------------------------------------------------------------
+// On real frame hashes 2.3e-4 of all pairs pass a 128-bit first stage (0.24 per 1024-pair tile) although only ~1e-8 are
 // hits. Every MFMA-based way of settling them spends matrix-pipe time on a whole 32x32 tile for ONE pair: +1 MFMA per
 // survivor in the register cascade (+11 % MFMAs and a dependent chain), 4 from memory in the fetch form. The queue form
-// spends none: the lanes that hold a surviving accumulator push (row, column) -- 4 bytes -- into a per-wave LDS queue, and
-// whenever 64 have gathered the wave settles them on the VALU, one pair per lane: the two FP4 images differ exactly in the
-// sign nibbles of differing bits, so hamming = popcount(x ^ y) over the 8 chunks. The matrix pipe never sees a survivor,
-// the query fragments stay at 128 bits (64 VGPRs at 8 tiles: the fetch form's MFMAs per B-fragment read), and the VALU,
-// which idles at ~35 % in this kernel, absorbs ~40 instructions per surviving tile + ~1.5 per settled pair.
-// A tile with MANY survivors (a real cluster, the diagonal, two copies of one video) still goes the tile route
-// (panel_survivors: full recomputation + the tile-level hit handler with its video-key de-duplication).
-// The queues are per wave (slots are handed out with a scalar counter, no atomics), but they are SETTLED by the whole
-// workgroup, right behind a super-panel barrier: a wave that settles its own queue sits out two memory round trips while its
-// three siblings run into the next barrier and wait for it (first version: SQ_WAIT_ANY +50 %, matrix pipe 0.50 busy). Behind
-// a barrier everybody is in step anyway; 256 lanes take one entry each, one round trip, every ~7 super-panels.
-constexpr uint32_t kQTileLanes = 4;   // a tile with survivors in more lanes (columns x halves) than this takes the tile route (4e-4 of the surviving tiles of frame hashes)
-constexpr uint32_t kQEntries = 1536;  // entries of all the workgroup's queues together (12 KB): 4 waves x 384 or 8 waves x 192
+// spends none: the panel loop is the fetch form's (v_alignbit shifts a tile's verdict into a per-lane mask), and once per
+// PANEL the lanes whose mask is not empty push it, with their column, branch-free: a ballot, two counts, one predicated
+// ds_write_b64 -- free next to 16 MFMAs. A mark stands for 8 accumulator registers of one tile (two marks per tile, one
+// v_alignbit each; registers 4c .. 4c+3 are four CONSECUTIVE rows, ibrel + 8c + 0..3, see qrow_of); mark number idx = 2 t + q
+// sits in bit (2 TILES - 1 - idx) of the mask. The queues are per wave (slots are handed out with a scalar counter, no
+// atomics) but SETTLED by the whole workgroup right behind a super-panel barrier, on the VALU: the packed hashes differ
+// exactly in the differing bits, so hamming = popcount(x ^ y); the filter looks at a mark's 8 rows against the column on the
+// 128 bits the first stage did NOT see -- the work of ONE lane per entry instead of wave-wide instructions per surviving tile
+// in the loop. A panel in which MANY lanes hold a survivor (a real cluster, the diagonal, two copies of one video) goes the
+// tile route (panel_survivors: full recomputation + the tile-level hit handler with its video-key de-duplication).
+// History of the forms that lost to this one (group-mask queue, 8-wave workgroups, 1 / 4 marks per tile): HISTORY.md.
+constexpr uint32_t kQEntries = 1536;  // entries of all the workgroup's queues together (12 KB): 4 waves x 384
 constexpr uint32_t kQMaxWaves = 8;
-#ifndef HVD_K2_QDRAIN_AT
-#define HVD_K2_QDRAIN_AT 700
-#endif
-constexpr uint32_t kQDrainAt = HVD_K2_QDRAIN_AT;   // settle when the workgroup holds this many: one round of drain_queues_wg (3 x 256) with the next super-panel's ~30 on top
-// entry: x = group mask of the lane's accumulator registers (bit 5 - g <-> a survivor among the registers of group g, see
-// or16_groups) | (first row of the tile, relative to the WAVE's first row: 32 t) << 16 (the wave is the queue's index);
-// y = column (absolute) << 1 | h (the lane's half: its rows start 4 h below the tile's first) -- hence n_pad < 2^31
+constexpr uint32_t kQDrainAt = 700;   // settle when the workgroup holds this many: one round of the filter (3 x 256) with the next super-panel's ~30 on top
+constexpr uint32_t kQPanelLanes = 48; // a panel in which more lanes than this hold a survivor takes the tile route (a tile full of hits has 64)
+constexpr int kQMarks = 2;            // marks per tile (1: 18.0, 2: 17.15, 4: 17.6 ms on frame hashes, profiles/r04_k2_queue_ablation.txt)
+// entry: x = the lane's marks; y = column (absolute) << 1 | h (the lane's half: its rows start 4 h below the tile's
+// first) -- hence n_pad < 2^31
 __shared__ uint2 g_wave_queue[kQEntries];  // wave w's queue: [w * qcap, (w + 1) * qcap), qcap = kQEntries / waves
 // Two sets of fill levels, used in turn: the words settle() of super-panel k reads behind its barrier are not the
 // words publish() of super-panel k+1 writes, so a wave that is late to read can never see a sibling's NEWER level and come to
@@ -574,177 +545,23 @@ __device__ __forceinline__ uint2* queue_entry(uint32_t k, const QCounts& c, uint
     return &g_wave_queue[w * qcap + (k - base)];
 }
 
+
 // Settling the workgroup's queues takes two LEAF functions, both called by all of its threads behind a barrier (the
 // caller puts another barrier behind them before anybody pushes again). Leaf, because a function that calls another keeps
 // its own values in the high callee-saved registers, and every register a callee touches is one the kernel cannot hold a
 // live value in across the call (a first version with nested calls: 167 VGPRs, 39 spills in the kernel's panel loop).
 //
-// 1. drain_filter_wg looks at the 128 bits the first stage did NOT see (other_half: 0 = bits 0..127) of the rows of each
-//    entry's first group, in the packed hashes: 16 B per hash; of unrelated pairs that agreed in one half, 2e-4 agree in the
-//    other. What this costs is line REQUESTS and rounds, not bytes (profiles/r04_k2_queue_ablation.txt): a lane's 16 bytes
-//    from a line of its own take the texture path a cycle each, and the other workgroups' panel prefetch queues behind
-//    them. So (a) the workgroup's own rows -- 1024 x 16 B -- are first copied, coalesced, into the panel buffer that is
-//    free at this point (rows_lds: 16 KB), and only an entry's COLUMN is a gather: one request per entry instead of four;
-//    (b) a thread takes three entries per round with their loads in flight together, and the queues are settled when they
-//    hold about one round's worth (kQDrainAt). The verdict goes back into the entry: x = groups still to do (bits 0..5) |
-//    rows of the first group that passed (bits 6..8) | the first group's number (bits 9..11) | row offset << 16.
-//    Returns non-zero if this thread left work for
-// 2. settle_marked_wg, which walks the same entries again: the rows that passed in full (settle_pair), an entry's further
-//    groups through the same filter first (rows_lds is still valid). Without packed hashes (image-only callers) every row
-//    of every group is its work.
-__device__ __noinline__ uint32_t drain_filter_wg(const HitCtx* __restrict__ ctx, uint32_t geom_v, uint32_t row0_v,
-                                                 uint32_t other_half_v, uint32_t tid, uint4* rows_generic) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    auto* rows_lds = (__attribute__((address_space(3))) uint4*)rows_generic;  // (ds_* instead of flat_* accesses)
-    const uint32_t geom = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom_v);
-    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
-    const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
-    const auto* cc = (const __attribute__((address_space(4))) HitCtx*)uniform_u64((unsigned long long)ctx);
-#else
-    uint4* rows_lds = rows_generic;
-    const uint32_t geom = geom_v, row0 = row0_v, ohw = other_half_v;
-    const HitCtx* cc = ctx;
-#endif
-    const uint32_t waves = geom & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;  // waves | tiles << 4 | entries per wave << 8 | marks per tile << 20 | set of fill levels << 24
-    const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
-    const uint32_t total = qc.pre[kQMaxWaves];
-    const uint4* __restrict__ db_q = cc->db_q;
-    const uint4* __restrict__ db_t = cc->db_t;
-    const uint32_t max_dist = cc->max_dist;
-    if (db_t == nullptr) return 1u;  // launch-uniform: no packed hashes, the entries stay as they are (every group to do)
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 6  // timing-only ablation: the call and nothing else
-    return 0u;
-#endif
-    const uint32_t ou = ohw & 3u, wrows = ohw >> 8;  // first unit of the other 128 bits | rows per wave << 8
-    {
-        const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;  // rows beyond it are padding: never queued, never read
-#pragma unroll
-        for (uint32_t r = tid; r < kSuper * 8u; r += nthreads) rows_lds[r] = other_block(db_q, (size_t)min(row0 + r, last), ou);
-        __syncthreads();
-    }
-    constexpr int E = 3;
-    uint32_t left = 0;
-#pragma unroll 1
-    for (uint32_t k0 = 0; k0 < total; k0 += nthreads * E) {
-        uint32_t ex[E];
-        uint4 col[E];
-#pragma unroll
-        for (int u = 0; u < E; ++u) {
-            const uint32_t k = k0 + tid + nthreads * (uint32_t)u;
-            ex[u] = 0u;
-            col[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (k < total) {
-                uint32_t w;
-                const uint2 e = *queue_entry(k, qc, qcap, &w);
-                // (bits 15, 12..14 are free: h and the wave ride along so that y and w need not be held)
-                ex[u] = e.x | ((e.y & 1u) << 15) | (w << 12);
-                col[u] = other_block(db_t, (size_t)(e.y >> 1), ou);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < E; ++u) {
-            const uint32_t k = k0 + tid + nthreads * (uint32_t)u;
-            if (k >= total) continue;
-            const uint32_t gm = ex[u] & 63u;
-            const uint32_t first = 31u - (uint32_t)__clz((int)gm);
-            const uint32_t rest = gm & ~(1u << first);
-            const uint32_t g = 5u - first, r0 = 3u * g;
-            const uint32_t ibrel = (ex[u] >> 16) + 4u * ((ex[u] >> 15) & 1u) + wrows * ((ex[u] >> 12) & 7u);  // relative to row0
-            // (group 5 = register 15 alone: its row three times)
-            const uint4 x0 = rows_lds[qrow_of(ibrel, r0)], x1 = rows_lds[qrow_of(ibrel, g == 5u ? r0 : r0 + 1u)],
-                        x2 = rows_lds[qrow_of(ibrel, g == 5u ? r0 : r0 + 2u)];
-            uint32_t pass = (sign_popc(x0, col[u], 0u) <= max_dist ? 1u : 0u) | (sign_popc(x1, col[u], 0u) <= max_dist ? 2u : 0u) |
-                            (sign_popc(x2, col[u], 0u) <= max_dist ? 4u : 0u);
-            if (g == 5u) pass &= 1u;
-            left |= pass | rest;
-            uint32_t w_;
-            queue_entry(k, qc, qcap, &w_)->x = (ex[u] & 0xFFFF0000u) | rest | (pass << 6) | (g << 9);
-        }
-    }
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 7  // timing-only ablation: the filter runs, nothing is settled
-    return 0u;
-#endif
-    return left;
-}
-
-__device__ __noinline__ void settle_marked_wg(const HitCtx* __restrict__ ctx, uint32_t geom_v, uint32_t row0_v,
-                                              uint32_t other_half_v, uint32_t tid, const uint4* rows_generic) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const auto* rows_lds = (const __attribute__((address_space(3))) uint4*)rows_generic;
-    const uint32_t geom = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom_v);
-    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
-    const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
-#else
-    const uint4* rows_lds = rows_generic;
-    const uint32_t geom = geom_v, row0 = row0_v, ohw = other_half_v;
-#endif
-    const uint32_t ou = ohw & 3u, wrows = ohw >> 8;  // first unit of the other 128 bits | rows per wave << 8
-    const uint32_t waves = geom & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;
-    const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
-    const HitCtx c = load_ctx(ctx);
-    const uint32_t total = qc.pre[kQMaxWaves];
-    const bool packed = c.db_t != nullptr;
-#pragma unroll 1
-    for (uint32_t k = tid; k < total; k += nthreads) {
-        uint32_t w;
-        const uint2 e = *queue_entry(k, qc, qcap, &w);
-        const uint32_t ibrel = (e.x >> 16) + 4u * (e.y & 1u) + wrows * w, j = e.y >> 1;
-        uint32_t gm = e.x & 63u, pass = (e.x >> 6) & 7u;
-        if ((gm | pass) == 0u) continue;
-        const uint32_t r0 = 3u * ((e.x >> 9) & 7u);
-#pragma unroll 1
-        while (pass != 0u) {  // rows of the first group that passed the filter
-            const uint32_t q = (uint32_t)__ffs((int)pass) - 1u;
-            pass &= pass - 1u;
-            settle_pair(c, row0 + qrow_of(ibrel, r0 + q), j);
-        }
-        if (gm == 0u) continue;
-        const uint4 col = packed ? other_block(c.db_t, (size_t)j, ou) : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll 1
-        while (gm != 0u) {  // the groups nobody has looked at yet
-            const uint32_t bit = 31u - (uint32_t)__clz((int)gm);
-            gm &= ~(1u << bit);
-            const uint32_t g = 5u - bit, nr = g == 5u ? 1u : 3u;
-#pragma unroll 1
-            for (uint32_t q = 0; q < nr; ++q) {
-                const uint32_t rr = qrow_of(ibrel, 3u * g + q);
-                if (packed && sign_popc(rows_lds[rr], col, 0u) > c.max_dist) continue;
-                settle_pair(c, row0 + rr, j);
-            }
-        }
-    }
-}
-
-// ---- panel-mark queue (QUEUE = 2, 3, 4: variants 17, 18, 19) ---------------------------------------------------------------
-// What the group-mask queue above still pays in the panel loop -- a taken branch and ~11 VALU instructions per SURVIVING TILE,
-// a fifth of all tiles of a frame-hash library, executed by a whole wave for the one lane that holds the survivor (1.2 + 0.4 ms
-// of 18.1 on 4.2e11 comparisons) -- moves behind the barrier as well: the panel loop is the fetch form's (v_alignbit shifts
-// a tile's verdict into a per-lane mask), and once per PANEL the lanes whose mask is not empty push it, with their column,
-// branch-free: a ballot, two counts, one predicated ds_write_b64 -- free next to 16 MFMAs (ablation: pushing and dropping costs
-// what not pushing costs). WHICH of the lane's rows it was is recorded only as far as the OR tree is cut: a mark stands for
-// 16 / Q accumulator registers of one tile (Q = 1, 2, 4 marks per tile, one v_alignbit each); registers 4c .. 4c+3 are four
-// CONSECUTIVE rows, ibrel + 8c + 0..3 (qrow_of). Mark number idx = t * Q + q sits in bit (TILES * Q - 1 - idx) of the mask.
-// The settlement filters a mark's 16 / Q rows against the column on the 128 bits the first stage did not see -- the work
-// of ONE lane per entry instead of wave-wide instructions per surviving tile in the loop. Q = 2 measures best (same box,
-// ms: Q = 1: 18.0, 2: 17.15, 4: 17.6; group masks: 18.25 -- the filter costs 0.2 + 0.125 ms per row of a mark, a mark 0.25 ms
-// in the loop). entry: x = the lane's marks; y as above. The filter writes back the marks that hold a HIT (x = 0: nothing
-// left; see HVD_K2_QFULL below), settle_marked_panel_wg walks those again and reports every row that passes in full.
-#ifndef HVD_K2_QPANEL_LANES
-#define HVD_K2_QPANEL_LANES 48
-#endif
-// a panel in which more lanes than this hold a survivor takes the tile route (16 / 32 / 48: the form beats the register form
-// up to 1.5 / 3.5 / 6.5 first-stage survivors per tile, profiles/r04_k2_queue_ablation.txt; a tile full of hits has 64)
-constexpr uint32_t kQPanelLanes = HVD_K2_QPANEL_LANES;
-
-#ifndef HVD_K2_QROT
-#define HVD_K2_QROT 1  // A/B: the filter's lanes walk their four rows in an order rotated by the lane number (measured neutral)
-#endif
-#ifndef HVD_K2_QE
-#define HVD_K2_QE 3  // entries a thread of the panel-mark settlement takes per round (2 .. 5 with matching kQDrainAt: within 1.5 %)
-#endif
-#ifndef HVD_K2_QFULL
-#define HVD_K2_QFULL 1  // A/B: a row that passes the filter is checked on the first stage's half as well, on the spot (-3.4 %)
-#endif
+// 1. drain_filter_panel_wg filters a mark's 8 rows against the entry's column on the 128 bits the first stage did NOT see,
+//    in the packed hashes: 16 B per hash; of unrelated pairs that agreed in one half, 2e-4 agree in the other. What this
+//    costs is line REQUESTS and rounds, not bytes (profiles/r04_k2_queue_ablation.txt): a lane's 16 bytes from a line of its
+//    own take the texture path a cycle each, and the other workgroups' panel prefetch queues behind them. So (a) the
+//    workgroup's own rows -- 1024 x 16 B -- are first copied, coalesced, into the panel buffer that is free at this point
+//    (rows_lds: 16 KB), and only an entry's COLUMN is a gather; (b) a thread takes three entries per round with their loads
+//    in flight together, and the queues are settled when they hold about one round's worth (kQDrainAt). The filter writes
+//    back the marks that hold a HIT (x = 0: nothing left). Returns non-zero if this thread left work for
+// 2. settle_marked_panel_wg, which walks the same entries again and reports every row that passes in full (settle_pair).
+//    Without packed hashes (image-only callers) every row of every mark is its work.
+// geom: waves | tiles << 4 | entries per wave << 8 | set of fill levels << 24
 #if defined(__HIP_DEVICE_COMPILE__)
 // Does any of four consecutive rows pass? Every lane's four rows start at a multiple of 64 bytes, so a ds_read_b128 that
 // takes the r-th row of every lane finds all of them in 4 of the 16 groups of four banks: the lanes walk their rows in an
@@ -753,33 +570,30 @@ __device__ __forceinline__ uint32_t filter_rows4(const __attribute__((address_sp
                                                  const uint4& col, uint32_t max_dist) {
     uint32_t pass = 0;
 #pragma unroll
-    for (uint32_t r = 0; r < 4u; ++r) pass |= sign_popc(rows[(r + (HVD_K2_QROT ? rot : 0u)) & 3u], col, 0u) <= max_dist ? 1u << r : 0u;
+    for (uint32_t r = 0; r < 4u; ++r) pass |= sign_popc(rows[(r + rot) & 3u], col, 0u) <= max_dist ? 1u << r : 0u;
     return pass;
 }
 #endif
-// geom: waves | tiles << 4 | entries per wave << 8 | marks per tile << 20
 __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict__ ctx, uint32_t geom_v, uint32_t row0_v,
                                                        uint32_t other_half_v, uint32_t tid, uint4* rows_generic) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    auto* rows_lds = (__attribute__((address_space(3))) uint4*)rows_generic;
+    auto* rows_lds = (__attribute__((address_space(3))) uint4*)rows_generic;  // (ds_* instead of flat_* accesses)
     const uint32_t geom = (uint32_t)__builtin_amdgcn_readfirstlane((int)geom_v);
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
     const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
     const auto* cc = (const __attribute__((address_space(4))) HitCtx*)uniform_u64((unsigned long long)ctx);
-    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = (geom >> 20) & 7u, nthreads = 64u * waves;
-    const uint32_t qshift = qg >> 1, chunks = 4u >> qshift, top = tiles * qg - 1u;  // qg = 1, 2, 4 -> shift 0, 1, 2; 4-row chunks per mark
+    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;
+    constexpr uint32_t qg = (uint32_t)kQMarks, qshift = qg >> 1, chunks = 4u >> qshift;  // 4-row chunks per mark
+    const uint32_t top = tiles * qg - 1u;
     const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
     const uint32_t total = qc.pre[kQMaxWaves];
     const uint4* __restrict__ db_q = cc->db_q;
     const uint4* __restrict__ db_t = cc->db_t;
     const uint32_t max_dist = cc->max_dist;
     if (db_t == nullptr) return 1u;  // launch-uniform: no packed hashes, every mark stays to do
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 6  // timing-only ablation: the call and nothing else
-    return 0u;
-#endif
-    const uint32_t ou = ohw & 3u, wrows = ohw >> 8;
-    const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;
-    constexpr int E = HVD_K2_QE;
+    const uint32_t ou = ohw & 3u, wrows = ohw >> 8;  // first unit of the other 128 bits | rows per wave << 8
+    const uint32_t last = (cc->rect != 0u ? cc->nq : cc->n) - 1u;  // rows beyond it are padding: never queued, never read
+    constexpr int E = 3;  // entries a thread takes per round (2 .. 5 with matching kQDrainAt: within 1.5 %)
     uint32_t left = 0;
     bool staged = false;
 #pragma unroll 1
@@ -808,10 +622,6 @@ __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict_
             __syncthreads();
             staged = true;
         }
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 9  // timing-only ablation: entries, columns and rows are fetched, nothing is filtered
-        asm volatile("" ::"v"(col[0].x ^ col[1].y ^ col[2].z ^ ex[0] ^ lanerel[1]));
-        continue;
-#endif
 #pragma unroll
         for (int u = 0; u < E; ++u) {
             const uint32_t k = k0 + tid + nthreads * (uint32_t)u;
@@ -827,11 +637,10 @@ __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict_
 #pragma unroll 1
                 for (uint32_t c = 0; c < chunks; ++c) {
                     uint32_t p4 = filter_rows4(rows_lds + ib + 8u * c, tid, col[u], max_dist);
-#if HVD_K2_QFULL
                     // A row that passes here by chance (2.3e-4 of them: one or two per settlement) would send the whole
                     // workgroup through settle_marked_panel_wg -- another walk over the queues and another memory round trip
                     // with everybody waiting. The lane that found it looks at the first stage's half as well, on the spot;
-                    // what it keeps is a hit.
+                    // what it keeps is a hit (A/B: -3.4 %).
                     if (__builtin_expect(p4 != 0u, 0)) {
                         uint32_t w2;
                         const uint32_t j = queue_entry(k, qc, qcap, &w2)->y >> 1;
@@ -842,13 +651,12 @@ __device__ __noinline__ uint32_t drain_filter_panel_wg(const HitCtx* __restrict_
                         while (p4 != 0u) {
                             const uint32_t r = (uint32_t)__ffs((int)p4) - 1u;
                             p4 &= p4 - 1u;
-                            const uint32_t rowrel = ib + 8u * c + ((r + (HVD_K2_QROT ? tid : 0u)) & 3u);
+                            const uint32_t rowrel = ib + 8u * c + ((r + tid) & 3u);
                             const size_t ri = (size_t)min(row0 + rowrel, last);
                             if (sign_popc(db_q[ri * 2u], c0, sign_popc(db_q[ri * 2u + 1u], c1, 0u)) <= max_dist) hit = 1u;
                         }
                         p4 = hit;
                     }
-#endif
                     pass |= p4;
                 }
                 if (pass != 0u) kept |= 1u << bit;
@@ -873,8 +681,9 @@ __device__ __noinline__ void settle_marked_panel_wg(const HitCtx* __restrict__ c
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0_v);
     const uint32_t ohw = (uint32_t)__builtin_amdgcn_readfirstlane((int)other_half_v);
     const uint32_t ou = ohw & 3u, wrows = ohw >> 8;
-    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, qg = (geom >> 20) & 7u, nthreads = 64u * waves;
-    const uint32_t qshift = qg >> 1, nrows = 16u >> qshift, top = tiles * qg - 1u;
+    const uint32_t waves = geom & 15u, tiles = (geom >> 4) & 15u, qcap = (geom >> 8) & 0xFFFu, nthreads = 64u * waves;
+    constexpr uint32_t qg = (uint32_t)kQMarks, qshift = qg >> 1, nrows = 16u >> qshift;
+    const uint32_t top = tiles * qg - 1u;
     const QCounts qc = load_qcounts(waves, (geom >> 24) & 1u);
     const HitCtx c = load_ctx(ctx);
     const uint32_t total = qc.pre[kQMaxWaves];
@@ -911,12 +720,11 @@ __device__ __noinline__ void settle_marked_panel_wg(const HitCtx* __restrict__ c
 // wave-uniform LDS base + lane*16, no VGPR round trip (so nothing to keep live -- or spill --
 // across the compute phase). The data is complete after the vmcnt(0) that hipcc places in
 // front of the next __syncthreads().
-template <int WAVES>
 __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src, uint4* lds_dst, uint32_t wave,
                                                   uint32_t lane) {
 #pragma unroll
-    for (int q = 0; q < kSuper * 8 / (64 * WAVES); ++q) {
-        const uint32_t chunk0 = (uint32_t)q * (64u * WAVES) + wave * 64u;  // first 16-B chunk of this wave-instruction
+    for (int q = 0; q < kSuper * 8 / 256; ++q) {
+        const uint32_t chunk0 = (uint32_t)q * 256u + wave * 64u;  // first 16-B chunk of this wave-instruction
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + chunk0 + lane),
             (__attribute__((address_space(3))) void*)(lds_dst + chunk0), 16, 0, 0);
@@ -925,25 +733,22 @@ __device__ __forceinline__ void stage_super_panel(const uint4* __restrict__ src,
 
 // The all-pairs kernel. Three numbers select the form (all exact, all bit-identical in their output):
 //   TILES  query tiles of 32 hashes per wave (4 waves per workgroup);
-//   S1     k-steps of the first stage: 4 = the whole 256-bit dot product at once; 2 = the first 128 bits, which
-//          bound the distance from below (a partial distance above the tolerance implies a full one above it), and
-//          only the rare tile that survives goes on to the other 128 bits;
-//   NBR    k-steps of the query fragments that live in registers: with S1 = 2 either 2 (the survivor's other half
-//          is fetched from memory: cheapest first stage, best when survivors are very rare -- uniform random
-//          hashes) or 4 (the second stage runs out of registers: robust when the first 128 bits of unrelated
-//          hashes often agree -- real frame hashes are far from uniform).
-// Each tile is judged on its own: reduce its 16 accumulators, one wave-uniform branch, and the survivors' second
-// stage / hit handler work on exactly that tile's accumulators -- nothing is recomputed.
-// RECT = false: img_q == img (one set, strict upper triangle). RECT = true: rows come from the
-// query image img_q (nq hashes), candidates from the target image img (n hashes), full rectangle.
-//   QUEUE  (NBR = S1 = 2 only) first-stage survivors are settled pair by pair on the VALU (pair queue, above) instead of
-//          tile by tile on the matrix pipe: the form for data on which false survivors are common (real frame hashes).
-//   WAVES  waves per workgroup: 4, or 8 (QUEUE with 4 tiles per wave: the same 1024 rows per workgroup and the same panels
-//          shared by twice as many, lighter waves -- <= 128 VGPRs = FOUR resident waves per SIMD. The pair-queue form lives on
-//          resident waves: 1 / 2 / 3 per SIMD take 40.6 / 23.0 / 18.2 ms on frame hashes, profiles/r04_k2_queue_ablation.txt).
-template <int TILES, int NBR, int S1, bool RECT, int QUEUE = 0, int WAVES = 4>
+//   S1     k-steps of the first stage: 4 = the whole 256-bit dot product at once; 2 = 128 bits, which bound the distance
+//          from below (a partial distance above the tolerance implies a full one above it), and only the rare tile that
+//          survives goes on to the other 128 bits;
+//   NBR    k-steps of the query fragments that live in registers: with S1 = 2 either 2 (the survivor's other half is
+//          fetched from memory: cheapest first stage, best when survivors are very rare -- uniform random hashes) or 4 (the
+//          second stage runs out of registers, 128 -> 192 -> 256 bits: robust when most tiles hold several survivors);
+//   QUEUE  (NBR = S1 = 2 only) first-stage survivors are settled pair by pair on the VALU (panel-mark queue, above) instead
+//          of tile by tile on the matrix pipe: the form for data on which false survivors are common (real frame hashes).
+// The forms that have a job (round 6; the others are in HISTORY.md): 8 = <8,4,4> the 256-bit reference; 9 = <8,2,2> fetch
+// (uniform data: the headline); 12 = <4,4,2> register cascade (dense data); 18 = <8,2,2,QUEUE> (frame hashes).
+// RECT = false: img_q == img (one set, strict upper triangle). RECT = true: rows come from the query image img_q (nq
+// hashes), candidates from the target image img (n hashes), full rectangle.
+// The query fragments are NEGATED and the accumulators start at (threshold - 1), so that a hit is a set sign bit (or16_bits).
+template <int TILES, int NBR, int S1, bool RECT, bool QUEUE = false>
 // (the 4-tile register form is held to 3 waves per SIMD = 168 VGPRs: with the pre-read fragment it would take 170)
-__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
+__global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
                                                           uint32_t max_dist, uint32_t col_chunk, uint32_t rank,
                                                           uint32_t world, const uint4* __restrict__ img_q, float scale2,
                                                           const HitCtx* __restrict__ ctx,
@@ -951,18 +756,29 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
     static_assert(S1 == 2 || S1 == 4, "first stage = 128 or 256 bits");
     static_assert(NBR >= S1 && (NBR == 2 || NBR == 4), "register-resident k-steps");
     static_assert(!QUEUE || (NBR == 2 && S1 == 2 && TILES <= 8), "the pair queue belongs to the 128-bit fetch form");
-    static_assert(WAVES == 4 || (WAVES == 8 && QUEUE), "8-wave workgroups exist for the pair-queue form");
+    constexpr int WAVES = 4;
     constexpr uint32_t WROWS = 32u * TILES, ROWS = (uint32_t)WAVES * WROWS, NT = 64u * WAVES;
-    // QUEUE: entries per wave, and the most one wave can add between two barriers
-    constexpr int QG = QUEUE == 2 ? 1 : QUEUE == 3 ? 2 : QUEUE == 4 ? 4 : 0;  // panel-mark queue: marks per tile
+    constexpr int QG = kQMarks;
     static_assert(TILES * QG <= 32, "a lane's marks are one word");
-    constexpr uint32_t QCAP = kQEntries / WAVES, QSUPERMAX = (kSuper / 32) * (QUEUE >= 2 ? kQPanelLanes : TILES * kQTileLanes);
+    // QUEUE: entries per wave, and the most one wave can add between two barriers
+    constexpr uint32_t QCAP = kQEntries / WAVES, QSUPERMAX = (kSuper / 32) * kQPanelLanes;
     static_assert(!QUEUE || QCAP >= QSUPERMAX + 64, "a wave's queue must take a super-panel's worth on top of a carry-over");
     __shared__ uint4 lds0[kSuper * 8], lds1[kSuper * 8];
 
-    // data-dependent choice between two forms of this kernel (launch_allpairs_auto): both are launched, the
-    // probe's verdict lets one of them run
+    // data-dependent choice between the forms of this kernel (launch_auto): all are launched, the probe's verdict lets one
+    // of them run
     if (select != nullptr && *select != select_id) return;
+    // Clock telemetry (round 6): one workgroup in eight brackets its lifetime with the shader-cycle counter (s_memtime) and the
+    // constant-rate counter (s_memrealtime) and adds both deltas to the context's accumulators -- effective shader clock of
+    // a pass = cycles / ticks x the tick rate, averaged over the sampled workgroups' lifetimes (hvd_debug_get "mfma_pass_khz").
+    // The start values wait in LDS (16 B), not in SGPRs: this kernel has no scalar register to spare (106 of 106, the queue
+    // form already parks 70 in VGPR lanes), and four more held across the tile cost form 9 its third resident wave.
+    if (threadIdx.x == 0u) {
+        const bool sample = ((blockIdx.x + blockIdx.y) & 7u) == 0u;
+        g_clk_t0[0] = sample ? (unsigned long long)__builtin_readcyclecounter() | 1ull : 0ull;  // (0 = not sampled)
+        g_clk_t0[1] = sample ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : 0ull;
+    }
+
     // Which 128 bits the first stage sees is the probe's choice too (select[3]): the image keeps bits 0..127 in chunks
     // 0..3 and bits 128..255 in chunks 4..7, so "the other half first" is chunk ^ 4 in every fragment address -- a
     // launch-uniform XOR into the slot swizzle. The full-distance paths sum over all eight chunks and do not care.
@@ -999,28 +815,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
         for (int s = 0; s < NBR; ++s) {
             const uint4 q = imgq[(size_t)hash * 8u + (img_slot(hash, 2u * s + h) ^ ((s & 1) ? selx1 : selx0))];
             // negated: flip the sign bit of every e2m1 nibble (see or16_bits)
-            const uint32_t fl = kSign ? 0x88888888u : 0u;
+            const uint32_t fl = 0x88888888u;
             a[t][s] = v4i{(int)(q.x ^ fl), (int)(q.y ^ fl), (int)(q.z ^ fl), (int)(q.w ^ fl)};
         }
     }
 
     // every product is +-v*v = +-scale2, so all dot products (and thresholds) scale by scale2.
-    // first stage: acc = c1 - dot over 64*S1 bits, hit candidate <=> acc < 0; the second stage of the register forms
+    // first stage: acc = c1 - dot over 64*S1 bits, hit candidate <=> acc < 0; the second stage of the register form
     // goes on to acc = c1 - dot256, a hit <=> dot256 >= 256 - 2*max_dist <=> acc <= c1 - thr_full = -129*scale2 (S1 = 2)
-    const float c1 = kSign ? scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist - 1.0f) : 0.0f;
+    const float c1 = scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist - 1.0f);
     const float hit2 = -128.5f * scale2;
     const float hit192 = -64.5f * scale2;  // after 192 bits: dot192 >= 192 - 2*max_dist <=> acc <= c1 - that = -65*scale2
-    const int thr192_bits = __float_as_int(scale2 * (192.0f - 2.0f * (float)max_dist));
-    const int thr1_bits = __float_as_int(scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist));  // plain form
-    const int thr2_bits = __float_as_int(scale2 * (256.0f - 2.0f * (float)max_dist));
     // marks' = marks << 1 | verdict(acc): v_alignbit_b32 takes the sign bit of the OR straight into the mask
     auto stage1_mark = [&](uint32_t marks, const v16f& acc) -> uint32_t {
-        if (kSign) return __builtin_amdgcn_alignbit(marks, (uint32_t)or16_bits(acc), 31);
-        return (marks << 1) | (max16_bits(acc) >= thr1_bits ? 1u : 0u);
+        return __builtin_amdgcn_alignbit(marks, (uint32_t)or16_bits(acc), 31);
     };
-    auto stage1_hit = [&](const v16f& acc) { return kSign ? __any(or16_bits(acc) < 0) : __any(max16_bits(acc) >= thr1_bits); };
-    auto stage2_hit = [&](const v16f& acc) { return kSign ? __any(min16(acc) < hit2) : __any(max16_bits(acc) >= thr2_bits); };
-    auto stage192_hit = [&](const v16f& acc) { return kSign ? __any(min16(acc) < hit192) : __any(max16_bits(acc) >= thr192_bits); };
+    auto stage1_hit = [&](const v16f& acc) { return __any(or16_bits(acc) < 0); };
+    auto stage2_hit = [&](const v16f& acc) { return __any(min16(acc) < hit2); };
+    auto stage192_hit = [&](const v16f& acc) { return __any(min16(acc) < hit192); };
 
     // candidates <= row0 cannot pair with rows >= row0 (i<j): start at the super-panel holding row0+1
     const uint32_t j0 = RECT ? col0 : max(col0, (row0 + 1u) & ~(uint32_t)(kSuper - 1));
@@ -1051,25 +863,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
             // survivor goes straight to its MFMA instead of waiting out an LDS round trip first (on frame hashes most
             // panels have one; same-box A/B on structured hashes: -2.5 %)
             v4i b192 = b[0];
-            if constexpr (NBR == 4 && S1 == 2 && kCascade) b192 = as_v4i(base[(4u + h) ^ sw0]);
+            if constexpr (NBR == 4 && S1 == 2) b192 = as_v4i(base[(4u + h) ^ sw0]);
 
             // two accumulator sets: the MFMAs of tile t+1 are issued before the max tree of tile t
-            if constexpr (QUEUE >= 2) {
+            if constexpr (QUEUE) {
                 // the fetch form's loop; what it marks is pushed once per panel, with no branch (panel-mark queue, above)
                 uint32_t marks = 0;  // bit (TILES * QG - 1 - (t * QG + q)) <-> registers 16 / QG * q ... of tile t
                 auto part_mark = [&](uint32_t mk, const v16f& acc) -> uint32_t {
-                    if constexpr (QG == 1) {
-                        return __builtin_amdgcn_alignbit(mk, (uint32_t)or16_bits(acc), 31);
-                    } else {
 #pragma unroll
-                        for (int q = 0; q < QG; ++q) {
-                            int x = 0;
+                    for (int q = 0; q < QG; ++q) {
+                        int x = 0;
 #pragma unroll
-                            for (int r = 0; r < 16 / QG; ++r) x |= __float_as_int(acc[16 / QG * q + r]);
-                            mk = __builtin_amdgcn_alignbit(mk, (uint32_t)x, 31);
-                        }
-                        return mk;
+                        for (int r = 0; r < 16 / QG; ++r) x |= __float_as_int(acc[16 / QG * q + r]);
+                        mk = __builtin_amdgcn_alignbit(mk, (uint32_t)x, 31);
                     }
+                    return mk;
                 };
                 v16f cur = tile_dot<0, S1>(a[0], b, zero);
 #pragma unroll
@@ -1082,101 +890,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
                 const unsigned long long act = __ballot(marks != 0u);
                 const uint32_t nl = (uint32_t)__builtin_popcount((uint32_t)act) + (uint32_t)__builtin_popcount((uint32_t)(act >> 32));
                 const bool dense = nl > kQPanelLanes;
-#if defined(HVD_K2_QABL) && (HVD_K2_QABL == 8 || HVD_K2_QABL == 10)  // timing-only ablation (wrong results): survivors are counted, nothing is pushed
-                asm volatile("" ::"s"(nl));
-#else
                 // (a second entry for the lanes that hold two marks -- 6 % of those that push; a settling wave is as slow as its
                 // lane with the most -- was measured: +1.5 %, the extra ballot and push in this loop cost more than they save)
+                // (the array stays NAMED in the store: through a bare LDS address the compiler cannot tell it from the panel
+                // buffers and waits for the prefetch in flight, vmcnt(0), first)
                 if (marks != 0u && !dense) {
                     const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
                     g_wave_queue[qidx + mb] = make_uint2(marks, ((jsp + 32u * p) << 1) + qcol);
                 }
                 qidx += dense ? 0u : nl;
-#endif
                 if (__builtin_expect(dense, 0)) {
-                    uint32_t tm = marks;  // one bit per tile for the tile route
-                    if constexpr (QG > 1) {
-                        tm = 0;
+                    uint32_t tm = 0;  // one bit per tile for the tile route
 #pragma unroll
-                        for (int t = 0; t < TILES; ++t) tm |= ((marks >> (QG * (TILES - 1 - t))) & ((1u << QG) - 1u)) != 0u ? 1u << (TILES - 1 - t) : 0u;
-                    }
+                    for (int t = 0; t < TILES; ++t) tm |= ((marks >> (QG * (TILES - 1 - t))) & ((1u << QG) - 1u)) != 0u ? 1u << (TILES - 1 - t) : 0u;
                     panel_survivors<TILES>(tm, imgq, panel, wrow0, jsp + 32u * p, lane, ctx);
                 }
-            } else if constexpr (QUEUE) {
-                // Each tile is judged while its accumulators are live; a surviving tile hands its few surviving PAIRS to the
-                // wave's queue (or, when there are many, its index to the tile route) and the matrix pipe moves on.
-                uint32_t tmarks = 0;  // wave-uniform: bit (TILES-1-t) <-> tile t takes the tile route
-                auto note = [&](const int t, const Or16Groups& o) {
-                    // ~13 VALU instructions: this kernel has ~10 VALU issue slots to spare per tile and a fifth of all tiles
-                    // of a frame-hash library come here, so every instruction of this path is on the clock. Which registers
-                    // of a lane hold the survivor is taken from the OR tree's six first-level results, not from the 16
-                    // accumulators (round 4: -11 instructions; the drain looks at up to three rows per entry instead).
-                    uint32_t gm = (uint32_t)o.g[0] >> 31;  // bit (5 - g) <-> group g
-#pragma unroll
-                    for (int g = 1; g < 6; ++g) gm = __builtin_amdgcn_alignbit(gm, (uint32_t)o.g[g], 31);
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 2  // timing-only ablation (wrong results): the mask is built, nothing is pushed
-                    asm volatile("" ::"v"(gm));
-                    return;
-#endif
-                    const unsigned long long act = __ballot(gm != 0u);
-                    // (two 32-bit counts: with the 64-bit one the compare below lands on the VALU)
-                    const uint32_t nl = (uint32_t)__builtin_popcount((uint32_t)act) + (uint32_t)__builtin_popcount((uint32_t)(act >> 32));
-#ifdef HVD_K2_QSTATS
-                    {
-                        const HitCtx cs = load_ctx(ctx);
-                        if (lane == 0u) {
-                            atomicAdd(&cs.qstats[0], 1ull);
-                            atomicAdd(&cs.qstats[3], (unsigned long long)nl);
-                            if (nl > kQTileLanes) atomicAdd(&cs.qstats[1], 1ull);
-                        }
-                    }
-#endif
-                    // no scalar branch in here: a dense tile only masks the push off and sets its mark
-                    const bool dense = nl > kQTileLanes;
-                    tmarks |= dense ? 1u << (TILES - 1 - t) : 0u;
-                    if (gm != 0u && !dense) {
-                        // Nothing in an entry but the mask is the lane's own business or the wave's: the tile is a literal, the
-                        // wave follows from the queue the entry sits in, the lane's half h rides in bit 0 of y next to the
-                        // column, whose lane-constant part is a register the loop holds anyway -- and the queue's index is the
-                        // fill level itself (qidx; the array stays NAMED in the store: through a bare LDS address the compiler
-                        // cannot tell it from the panel buffers and waits for the prefetch in flight, vmcnt(0), first).
-                        // Every per-lane or per-wave constant tried here ended up spilled (a scratch
-                        // reload whose vmcnt(0) also waits for the panel prefetch; v_readlane of spilled SGPRs), in a path that
-                        // a fifth of all tiles take.
-                        const uint32_t mb = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-                        g_wave_queue[qidx + mb] = make_uint2(gm | ((32u * (uint32_t)t) << 16), ((jsp + 32u * p) << 1) + qcol);
-                    }
-                    qidx += dense ? 0u : nl;
-                };
-                static_assert(kSign, "the pair-queue form reads sign bits (HVD_K2_SIGN=1)");
-                auto hit = [&](const Or16Groups& o) { return __any(o.all < 0); };
-                // A VALU read of a register an MFMA is still writing is a SOFTWARE-managed hazard on gfx950 (the compiler
-                // normally inserts s_nop wait states). Here hipcc 7.2's scheduler moved the first two v_or3 of a tile's tree
-                // in front of the NEXT tile's MFMAs, into a basic block with several predecessors right behind the judged
-                // tile's in-place MFMA, and its hazard recogniser lost track: half-written accumulators were read and 0.4 %
-                // of the planted pairs went missing (scripts/gpu_k2_missing.py: all in tile 1, registers 2, 4, 5). The order
-                // is therefore pinned: both MFMAs of tile t+1 are ISSUED before anything of tile t's tree -- the second of
-                // them depends on the first, which cannot start before tile t's last MFMA has left the in-order pipe, so
-                // the tree reads finished registers whatever the recogniser counts. (An explicit s_nop 11 in front of every
-                // tree is also correct, but comes on top of the compiler's own waits: +5 % on uniform data.)
-                auto judge = [&](const v16f& acc) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    return or16_groups(acc);
-                };
-                v16f cur = tile_dot<0, S1>(a[0], b, zero);
-#pragma unroll
-                for (int t = 1; t < TILES; ++t) {
-                    const v16f nxt = tile_dot<0, S1>(a[t], b, zero);
-                    const Or16Groups o = judge(cur);
-                    if (__builtin_expect(hit(o), 0)) note(t - 1, o);
-                    cur = nxt;
-                }
-                {
-                    const Or16Groups o = judge(cur);
-                    if (__builtin_expect(hit(o), 0)) note(TILES - 1, o);
-                }
-                // (both calls sit where no accumulator is live: the handlers' registers add to the live set across a call)
-                if (__builtin_expect(tmarks != 0u, 0)) panel_survivors<TILES>(tmarks, imgq, panel, wrow0, jsp + 32u * p, lane, ctx);
             } else if constexpr (NBR == 2) {
                 // survivors are only noted -- one VALU op per tile shifts the tile's verdict (the sign of the OR, or the
                 // compare's result) into a per-lane mask -- and dealt with after the panel, when no accumulator is live
@@ -1196,22 +924,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
                 // tile with a real hit (all 256 bits) calls the handler
                 auto survivor = [&](const int t, v16f acc) {
                     if (S1 == 2) {
-                        // cascade 128 -> 192 -> 256 bits (every partial distance bounds the full one from below): on real
-                        // frame hashes 2e-4 of all pairs pass the first 128 bits, i.e. most (wave, panel) steps see a
-                        // false survivor -- it now costs ONE more MFMA, and only what also survives 192 bits a second
-                        if (kCascade) {
-                            acc = mfma_fp4(a[t][2], b192, acc);
-                            if (!stage192_hit(acc)) return;
-                            acc = mfma_fp4(a[t][3], as_v4i(base[(6u + h) ^ sw1]), acc);
-                        } else {
-                            v4i b2[2];
-#pragma unroll
-                            for (int s = 0; s < 2; ++s) b2[s] = as_v4i(base[(2u * (s + 2) + h) ^ (s ? sw1 : sw0)]);
-                            acc = tile_dot<0, 2>(&a[t][2], b2, acc);
-                        }
+                        // cascade 128 -> 192 -> 256 bits (every partial distance bounds the full one from below): on dense
+                        // data most (wave, panel) steps see a false survivor -- it costs ONE more MFMA, and only what also
+                        // survives 192 bits a second
+                        acc = mfma_fp4(a[t][2], b192, acc);
+                        if (!stage192_hit(acc)) return;
+                        acc = mfma_fp4(a[t][3], as_v4i(base[(6u + h) ^ sw1]), acc);
                         if (!stage2_hit(acc)) return;
                     }
-                    tile_hits<kSign>(acc, wrow0 + 32u * (uint32_t)t, jsp + cl, lane, ctx);
+                    tile_hits<true>(acc, wrow0 + 32u * (uint32_t)t, jsp + cl, lane, ctx);
                 };
                 v16f cur = tile_dot<0, S1>(a[0], b, zero);
 #pragma unroll
@@ -1226,62 +947,42 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : ((TILES == 4 && NBR ==
     };
 
     // QUEUE: every wave publishes its fill level in front of a super-panel barrier; behind it the workgroup decides -- on
-    // the same four numbers -- whether to settle the queues now (drain_queues_wg).
-    const uint32_t drain_at = kQDrainAt;
+    // the same four numbers -- whether to settle the queues now.
     auto publish = [&](const uint32_t par) {
         if constexpr (QUEUE) {
             if (lane == 0u) g_wave_qn[par][wave] = qidx - wave * QCAP;
         }
     };
     auto settle = [&](const bool final, uint4* free_panel, const uint32_t par) {
-#if defined(HVD_K2_QABL) && HVD_K2_QABL == 10  // timing-only ablation: (with nothing pushed) no look at the fill levels either
-        return;
-#endif
         if constexpr (QUEUE) {
             const QCounts qc = load_qcounts(WAVES, par);
             const uint32_t sum = qc.pre[kQMaxWaves];
             uint32_t mx = 0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) mx = max(mx, qc.pre[w + 1] - qc.pre[w]);
-            if (final ? sum != 0u : (sum >= drain_at || mx > QCAP - QSUPERMAX)) {
-#ifdef HVD_K2_QSTATS
-                if (wave == 0u && lane == 0u) {
-                    const HitCtx cs = load_ctx(ctx);
-                    atomicAdd(&cs.qstats[4], 1ull);
-                    atomicAdd(&cs.qstats[5], (unsigned long long)sum);
-                    if (final) atomicAdd(&cs.qstats[6], 1ull);
-                    else if (sum < kQDrainAt) atomicAdd(&cs.qstats[7], 1ull);
-                }
-#endif
-#if !(defined(HVD_K2_QABL) && HVD_K2_QABL == 3)  // 3 = pushed entries are dropped instead of settled
-                const uint32_t GEOM = (uint32_t)WAVES | ((uint32_t)TILES << 4) | (QCAP << 8) | ((uint32_t)QG << 20) | (par << 24);
-                if constexpr (QUEUE >= 2) {
-                    const uint32_t left = drain_filter_panel_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
-                    if (__builtin_expect(__any(left != 0u), 0)) settle_marked_panel_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
-                } else {
-                    const uint32_t left = drain_filter_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
-                    if (__builtin_expect(__any(left != 0u), 0)) settle_marked_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
-                }
-#endif
+            if (final ? sum != 0u : (sum >= kQDrainAt || mx > QCAP - QSUPERMAX)) {
+                const uint32_t GEOM = (uint32_t)WAVES | ((uint32_t)TILES << 4) | (QCAP << 8) | (par << 24);
+                const uint32_t left = drain_filter_panel_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
+                if (__builtin_expect(__any(left != 0u), 0)) settle_marked_panel_wg(ctx, GEOM, row0, other_unit_of(sel) | (WROWS << 8), wave * 64u + lane, free_panel);
                 qidx = wave * QCAP;
                 __syncthreads();  // nobody pushes (or publishes) again before everybody has read the queues
             }
         }
     };
 
-    stage_super_panel<WAVES>(img + (size_t)j0 * 8u, lds0, wave, lane);
+    stage_super_panel(img + (size_t)j0 * 8u, lds0, wave, lane);
     __syncthreads();
 
     for (uint32_t sp = 0; sp < nsp; sp += 2) {
         const uint32_t jsp = j0 + sp * kSuper;
         // lds1 was last read in iteration sp-1, which every wave left through a barrier
-        if (sp + 1u < nsp) stage_super_panel<WAVES>(img + (size_t)(jsp + kSuper) * 8u, lds1, wave, lane);
+        if (sp + 1u < nsp) stage_super_panel(img + (size_t)(jsp + kSuper) * 8u, lds1, wave, lane);
         process(lds0, jsp);
         publish(0u);
         __syncthreads();  // (drains the in-flight global->LDS loads with vmcnt(0) first)
         if (sp + 1u >= nsp) break;
         settle(false, lds0, 0u);  // (lds0 has just been used up and is not refilled before the settlement is over)
-        if (sp + 2u < nsp) stage_super_panel<WAVES>(img + (size_t)(jsp + 2u * kSuper) * 8u, lds0, wave, lane);
+        if (sp + 2u < nsp) stage_super_panel(img + (size_t)(jsp + 2u * kSuper) * 8u, lds0, wave, lane);
         process(lds1, jsp + kSuper);
         publish(1u);
         __syncthreads();
@@ -1387,6 +1088,11 @@ __global__ void k_set_hit_ctx(HitCtx* __restrict__ dst, const HitCtx src, uint32
     }
 }
 
+// the clock telemetry's accumulators (HitCtx::clk): cycles, ticks, sampled workgroups, spare
+__global__ void k_clk_reset(unsigned long long* clk) {
+    clk[0] = clk[1] = clk[2] = clk[3] = 0ull;
+}
+
 // survivors among `pairs` sampled pairs -> form. The fetch form (id_rare) pays ~6 panel steps per surviving TILE: right when
 // survivors are real near-duplicates (uniform random hashes). The pair-queue form (id_mid) pays the settlement of one queue
 // entry per surviving lane and nothing on the matrix pipe: right for real frame hashes, whose first 128 bits agree within the
@@ -1428,6 +1134,7 @@ uint32_t fp4_rows_padded(uint32_t n) { return round_up(n ? n : 1, 1024u); }
 // e2m1 code of the magnitude used for the +-v image: 1 = 0.5, 2 = 1.0 (default), 4 = 2.0, 6 = 4.0.
 // Any of them is exact; the choice only changes what toggles in the multiplier array (power -> clock).
 uint32_t g_fp4_code = 2;
+constexpr int kClkWord = 192;  // 32-bit word offset of the clock telemetry's accumulators in a context's select buffer (byte 768)
 static float fp4_scale2() {
     const float v = g_fp4_code == 1 ? 0.5f : g_fp4_code == 2 ? 1.0f : g_fp4_code == 4 ? 2.0f : 4.0f;
     return v * v;
@@ -1441,8 +1148,8 @@ hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStrea
     return hipGetLastError();
 }
 
-// auto variant (13): the form for data with common false survivors (15 = pair queue; 0 = none, i.e. round 3's two-way choice)
-// and the survivor density (per 1024-pair tile, as the probe estimates it) up to which it is preferred over the register form
+// auto variant (13): the form for data with common false survivors (18 = panel-mark queue; 0 = none, i.e. round 3's two-way
+// choice) and the survivor density (per 1024-pair tile, as the probe estimates it) up to which it is preferred over the register form
 uint32_t g_mfma_lds_pad = 0;  // occupancy experiments: unused dynamic LDS per workgroup (hvd_debug_set "mfma_lds_pad")
 uint32_t g_mfma_queue_packed = 1;  // 0: the pair queue settles from the FP4 images even when packed hashes are at hand (tests)
 uint32_t g_mfma_auto_mid = 18;
@@ -1492,20 +1199,14 @@ static uint32_t pick_col_chunk_m(uint32_t n_pad, uint32_t rows_per_wg) {
 struct MfmaForm {
     int tiles, nbr, s1, waves = 4;
 };
-// variants: 8 = 256 bits at once; 9 = 128-bit first stage, survivors fetch their other half (default for uniform
-// data); 10 / 11 = the same with 4 tiles per wave; 12 = 128-bit first stage, second stage out of registers (4 tiles);
-// 13 = 9 or 12, chosen per launch by the probe.
+// variants: 8 = 256 bits at once (the reference form); 9 = 128-bit first stage, survivors fetch their other half (uniform
+// data); 12 = 128-bit first stage, second stage out of registers (4 tiles; dense data); 18 = 128-bit first stage, survivors
+// through the panel-mark queue (frame hashes); 13 = 9, 18 or 12, chosen per launch by the probe.
 static bool mfma_form(int variant, MfmaForm* f) {
     switch (variant) {
         case 8: *f = {8, 4, 4}; return true;
-        case 9: case 13: *f = {8, 2, 2}; return true;
-        case 10: *f = {4, 4, 4}; return true;
-        case 11: *f = {4, 2, 2}; return true;
+        case 9: case 13: case 18: *f = {8, 2, 2}; return true;
         case 12: *f = {4, 4, 2}; return true;
-        case 14: *f = {8, 4, 2}; return true;  // experiment: register form with 8 tiles per wave (2 waves/SIMD)
-        case 15: *f = {8, 2, 2}; return true;  // pair-queue form: survivors settled pair by pair on the VALU
-        case 16: *f = {4, 2, 2, 8}; return true;
-        case 17: case 18: case 19: *f = {8, 2, 2}; return true;  // panel-mark queue: the fetch form's loop, survivors pushed once per panel  // the same with 8 waves of 4 tiles per workgroup: 4 resident waves per SIMD
         default: return false;
     }
 }
@@ -1540,17 +1241,17 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
     if (c.db_q == nullptr || c.db_t == nullptr || !g_mfma_queue_packed) c.db_q = c.db_t = nullptr;
     c.max_dist = a.max_dist;
     uint32_t* sel = nullptr;
-    c.qstats = mfma_select_buffer(a.ctx_id, &sel) == hipSuccess ? reinterpret_cast<unsigned long long*>(sel + 128) : nullptr;
+    c.clk = mfma_select_buffer(a.ctx_id, &sel) == hipSuccess ? reinterpret_cast<unsigned long long*>(sel + kClkWord) : nullptr;
     return c;
 }
 
 // One launch of one form. rect: rows = the nq hashes of d_img_q, columns = the a.n hashes of d_img.
-template <int T, int NBR, int S1, int QUEUE = 0, int WAVES = 4>
+template <int T, int NBR, int S1, bool QUEUE = false>
 static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rect, const void* d_img_q, uint32_t nq,
                               const int32_t* d_group_t, const uint32_t* d_select, uint32_t select_id, hipStream_t s,
                               bool write_ctx = true) {
     const uint32_t n_pad = fp4_rows_padded(a.n);
-    constexpr uint32_t ROWS = 32u * T * WAVES;
+    constexpr uint32_t ROWS = 32u * T * 4u;
     const uint32_t nrows = rect ? nq : a.n;
     const uint64_t n_rb = (nrows + ROWS - 1) / ROWS;
     uint64_t chunk;
@@ -1575,11 +1276,11 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
         hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1, rect ? d_img_q : d_img, d_img),
                            (uint32_t*)nullptr);
     if (rect)
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE, WAVES>), grid, dim3(64 * WAVES), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE>), grid, dim3(256), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
                            select_id, (uint32_t)(g_mfma_force_sel > 0 ? g_mfma_force_sel : 0));
     else
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE, WAVES>), grid, dim3(64 * WAVES), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE>), grid, dim3(256), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
                            a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)nullptr, fp4_scale2(), ctx, d_select,
                            select_id, (uint32_t)(g_mfma_force_sel > 0 ? g_mfma_force_sel : 0));
     return hipGetLastError();
@@ -1591,15 +1292,8 @@ static hipError_t launch_variant(int variant, const AllPairsArgs& a, const void*
     switch (variant) {
         case 8: return launch_form<8, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 8u, s, write_ctx);
         case 9: return launch_form<8, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 9u, s, write_ctx);
-        case 10: return launch_form<4, 4, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 10u, s, write_ctx);
-        case 11: return launch_form<4, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 11u, s, write_ctx);
         case 12: return launch_form<4, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 12u, s, write_ctx);
-        case 14: return launch_form<8, 4, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 14u, s, write_ctx);
-        case 15: return launch_form<8, 2, 2, 1>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 15u, s, write_ctx);
-        case 16: return launch_form<4, 2, 2, 1, 8>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 16u, s, write_ctx);
-        case 17: return launch_form<8, 2, 2, 2>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 17u, s, write_ctx);
-        case 18: return launch_form<8, 2, 2, 3>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 18u, s, write_ctx);
-        case 19: return launch_form<8, 2, 2, 4>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 19u, s, write_ctx);
+        case 18: return launch_form<8, 2, 2, true>(a, d_img, rect, d_img_q, nq, d_group_t, d_select, 18u, s, write_ctx);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1619,7 +1313,7 @@ hipError_t mfma_select_buffer(int ctx_id, uint32_t** out) {
     std::lock_guard<std::mutex> lk(alloc_mu);
     if (!g_select[ctx_id]) {
         static_assert(sizeof(HitCtx) <= 192, "hit context does not fit its slot");
-        // 16 B of select words, the hit context at +64, 16 counters of HVD_K2_QSTATS builds at +512
+        // 24 B of select words, the hit context at +64, the clock telemetry's four accumulators at +768 (kClkWord)
         uint32_t* p = nullptr;
         hipError_t e = hipMalloc((void**)&p, 1024);
         // (hipMemset on device memory does not wait: without the synchronisation it can land on top of the first context
@@ -1634,6 +1328,24 @@ hipError_t mfma_select_buffer(int ctx_id, uint32_t** out) {
     }
     *out = g_select[ctx_id];
     return hipSuccess;
+}
+
+// Clock telemetry of the all-pairs passes of one context (k_allpairs_mfma): reset enqueues the zeroing on the stream; read
+// waits for the stream and returns the accumulators {shader cycles, constant-rate ticks, sampled workgroups, 0}.
+hipError_t mfma_clock_reset(int ctx_id, hipStream_t s) {
+    uint32_t* sel = nullptr;
+    hipError_t e = mfma_select_buffer(ctx_id, &sel);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_clk_reset, dim3(1), dim3(1), 0, s, reinterpret_cast<unsigned long long*>(sel + kClkWord));
+    return hipGetLastError();
+}
+
+hipError_t mfma_clock_read(int ctx_id, hipStream_t s, unsigned long long out[4]) {
+    uint32_t* sel = nullptr;
+    hipError_t e = mfma_select_buffer(ctx_id, &sel);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(out, sel + kClkWord, 32, hipMemcpyDeviceToHost, s);
+    return e == hipSuccess ? hipStreamSynchronize(s) : e;
 }
 
 void mfma_release() {
@@ -1680,13 +1392,9 @@ static hipError_t launch_auto(const AllPairsArgs& a, const void* d_img, bool rec
 }
 
 static int effective_variant(int variant, uint32_t max_dist, uint32_t n) {
-    if (variant >= 15 && variant <= 19 && fp4_rows_padded(n) >= (1u << 31)) variant = 12;  // the pair queue keeps (column << 1 | half) in 32 bits
+    if (variant == 18 && fp4_rows_padded(n) >= (1u << 31)) variant = 12;  // the pair queue keeps (column << 1 | half) in 32 bits
     // the 128-bit first stage needs 128 - 2*max_dist > 0
-    if (max_dist >= 64u) {
-        if (variant == 9 || variant == 13 || (variant >= 15 && variant <= 19)) return 8;
-        if (variant == 11 || variant == 12) return 10;
-        if (variant == 14) return 8;
-    }
+    if (max_dist >= 64u && (variant == 9 || variant == 12 || variant == 13 || variant == 18)) return 8;
     return variant;
 }
 

@@ -48,6 +48,40 @@ MATCH_COMPARATOR = os.environ.get("HVD_MATCH_COMPARATOR", "le")
 _COMPARATORS = ("le", "lt")
 
 
+def policy_labels() -> dict:
+    """The semantic switches the absent `hvdaccelerators` wheel leaves open, as labels for every artefact that reports
+    results (bench.py's JSON line, hvd_runtime_info): `(unverified)` marks a DEFAULT that nothing reference-held confirms;
+    a value set explicitly through the environment is the caller's decision and carries no mark."""
+    return {"comparator": MATCH_COMPARATOR + ("" if "HVD_MATCH_COMPARATOR" in os.environ else " (unverified)"),
+            "reduction": MATCH_POLICY + ("" if "HVD_MATCH_POLICY" in os.environ else " (unverified)"),
+            "dct": "strict" if _lib_dct_mode() == 0 else "fma",
+            "hash_text": "hex, 64 characters per frame (unverified)"}
+
+
+def _lib_dct_mode() -> int:
+    try:
+        return int(_lib.load().hvd_get_pdq_dct_mode())
+    except Exception:  # noqa: BLE001 - labels must be printable without the library
+        return 0 if os.environ.get("HVD_PDQ_DCT_MODE", "strict") != "fma" else 1
+
+
+_warned_unverified = False
+
+
+def warn_unverified_policies() -> None:
+    """One RuntimeWarning per process, the first time a matchHash* entry runs with the comparator left at its unverified
+    default: upstream's matchTwoHashBrute may compare with a strict `<`."""
+    global _warned_unverified
+    if _warned_unverified or "HVD_MATCH_COMPARATOR" in os.environ:
+        return
+    _warned_unverified = True
+    import warnings
+
+    warnings.warn("hvd_amd: frame comparator left at its default 'le' (a frame pair at Hamming distance == tolerance is a hit); "
+                  "hvdaccelerators 0.4.0 could not be consulted and upstream vPDQ may use a strict '<'. Set "
+                  "HVD_MATCH_COMPARATOR=le|lt to state the choice (INTEGRATION.md section 4).", RuntimeWarning, stacklevel=3)
+
+
 def frame_max_dist(distance_tolerance, comparator: str | None = None) -> int:
     """Inclusive Hamming bound the kernels use for a reference-style tolerance under the comparator
     policy: tolerance for "le", tolerance - 1 for "lt" (-1 = nothing matches)."""
@@ -352,6 +386,8 @@ def match_counts(a: bytes, b: bytes, distance_tolerance: int = 31) -> tuple[int,
 
 def matchHashBytes(a: bytes, b: bytes, distance_tolerance: int) -> float:
     """db/vptree.py:31 call shape: similarity in [0,100] from two raw BLOBs."""
+    if not _warned_unverified:
+        warn_unverified_policies()
     max_dist = frame_max_dist(distance_tolerance)
     if max_dist < 0:
         if len(a) % BYTES_PER_PDQ_HASH or len(b) % BYTES_PER_PDQ_HASH:

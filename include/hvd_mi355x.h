@@ -211,23 +211,24 @@ int hvd_get_pdq_dct_mode(void);
  *   "pdq_down512_wave_grid" n                              (waves in flight; 0 = what is resident at once)
  *   "pdq_down512_strip" 0|32|64                            (workgroup-per-frame kernel's strip width: by batch size | 32 | 64)
  *   "fp4_code", "mfma_col_chunk_max"                       (FP4-MFMA Hamming kernel)
- *   "mfma_auto_mid" 0|15..19, "mfma_auto_mid_max_x100" n   (auto variant: the pair-queue form it may pick -- 18 -- and the survivor
- *                                                           density per 1024-pair tile, x 0.01, up to which it does -- 500)
+ *   "mfma_auto_mid" 0|18, "mfma_auto_mid_max_x100" n       (auto variant: may it pick the panel-mark queue form -- 18 -- and the
+ *                                                           survivor density per 1024-pair tile, x 0.01, up to which it does -- 500)
  *   "mfma_queue_packed" 0|1, "mfma_lds_pad" bytes          (pair queue settles from the FP4 images only; occupancy experiments)
  *   "mfma_force_sel" -1|0|1|2                              (which 128 bits the first stage sees: the probe's choice | bits 0..127 |
  *                                                           128..255 | 0..63 + 192..255)
  *   "pdq_hash_grid" n, "pdq_hash_prefetch" 0|1             (64x64 hash kernel: forced grid; next frame fetched ahead, off)
  *   "vmatch_exchange" 0|1|2                                (key exchange of the video search: iff world > 1 | always | never)
  *   "vmatch_slots_log2" 0|4..30                            (initial size of the video-reduction tables; tests the regrowth)
- *   "vmatch_variant" 0|8..19                               (all-pairs form of the video-level searches; 0 = the auto variant)
+ *   "vmatch_variant" 0|8|9|12|13|18                        (all-pairs form of the video-level searches; 0 = the auto variant)
  *   "vmatch_bit_order" 0|1|2                               (video search: hashes rewritten with the 128 least entangled bits first: never |
  *                                                           from 65 536 frames on (default) | always; results never change)
  *   "match_server" 0|1                                     (hvd_match_two, small operands: one launch per call | a workgroup that stays
  *                                                           resident between calls and polls pinned host memory -- the default)
  *   "copy_nt" 0|1                                          (hvd_hasher_push: plain memcpy | non-temporal stores where the CPU has them)
+ *   "mfma_clock_reset" 1                                   (telemetry: clear this context's clock accumulators, in stream order)
  * Unknown keys and out-of-range values return HVD_ERR_ARG. */
 int hvd_debug_set(const char* key, int value);
-/* "mfma_auto_form": the form (9, 18 or 12; 15..19 if "mfma_auto_mid" says so) the last auto-variant launch ran;
+/* "mfma_auto_form": the form (9, 18 or 12) the last auto-variant launch ran;
  * "mfma_probe_survivors" / "mfma_probe_survivors_hi" / "mfma_probe_survivors_mix": what its probe counted over bits 0..127 /
  * 128..255 / 0..63 + 192..255; "mfma_auto_half": the selection the first stage ran on (0 / 1 / 2 in that order).
  * Synchronises the library stream.
@@ -237,7 +238,11 @@ int hvd_debug_set(const char* key, int value);
  * AVX2 | AVX-512 streaming stores in hvd_hasher_push (hvd_debug_set "copy_nt" 0|1; HVD_COPY_NT=0 in the environment).
  * "vmatch_bit_order_used": 1 if the last video search on this context rewrote its hashes in a chosen bit order.
  * "hasher_us_copy" / "hasher_us_submit" / "hasher_us_wait": host microseconds the streaming hashers of this process spent copying
- * frames into the ring, enqueueing batches and waiting for a slot since the last read (reading clears). */
+ * frames into the ring, enqueueing batches and waiting for a slot since the last read (reading clears).
+ * "mfma_pass_khz": the shader clock (kHz) the FP4-MFMA all-pairs passes of this context ran at since the last
+ * "mfma_clock_reset": one workgroup in eight brackets its lifetime with s_memtime (shader cycles) and s_memrealtime (constant
+ * rate); cycles / ticks x hipDeviceAttributeWallClockRate. "mfma_clock_samples": how many workgroups contributed (0: none,
+ * and "mfma_pass_khz" reads 0). Both wait for the library stream. */
 int hvd_debug_get(const char* key, int* out_value);
 
 /* Bytes of device scratch hvd_dev_pdq_hash_frames needs for this geometry (0 for
@@ -251,11 +256,12 @@ int hvd_dev_pdq_hash_frames(const void* d_frames, int64_t n, int h, int w, int c
 /* Brute-force pass over the tiles owned by `rank` of `world` (tile (rb,cb) belongs
  * to rank (rb+cb) % world; world=1 => everything). Appends hvd_pair records to
  * d_pairs[cap] and bumps the uint64 at d_count (the caller zeroes it). Records are
- * unordered. variant: 0 = default kernel; see DESIGN.md for the others. */
+ * unordered. variant: 0 = the integer form of the north star (8 xor + 8 popcount per comparison), 1 = the same behind a
+ * 128-bit prefilter (the independent path of the full-size parity tests). */
 int hvd_dev_allpairs_hamming256(const void* d_db, int64_t n, const void* d_group, int max_dist, int rank, int world,
                                 void* d_pairs, int64_t cap, void* d_count, int variant);
 
-/* Matrix-core form of the same pass (variants 8..19): the DB is first
+/* Matrix-core form of the same pass (variants 8, 9, 12, 18 and 13 = chosen per launch by a probe): the DB is first
  * rewritten as its FP4 image (every bit b as the e2m1 number 1-2b; 128 bytes per hash,
  * rows padded to a multiple of 1024), then v_mfma_f32_32x32x64_f8f6f4 produces
  * 256 - 2*hamming for 32x32 pairs at a time. Output contract identical to

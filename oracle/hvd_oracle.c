@@ -501,9 +501,9 @@ static void* pair_worker(void* arg) {
 /* Brute-force ground truth of the pair predicate (finding 5):
  * all i<j with hamming(db[i], db[j]) <= max_dist (and group[i] != group[j] when
  * group is given). Output is sorted by (i, j). Rows [row_begin,row_end) only. */
-int hvd_cpu_allpairs_hamming256_rows(const uint8_t* db, int64_t n, const int32_t* group, int64_t row_begin,
-                                     int64_t row_end, int max_dist, hvd_pair* out, int64_t cap,
-                                     int64_t* out_count, int num_threads) {
+static int allpairs_rows_impl(const uint8_t* db, int64_t n, const int32_t* group, int64_t row_begin, int64_t row_end,
+                              int max_dist, hvd_pair* out, int64_t cap, int64_t* out_count, int num_threads,
+                              uint64_t* tdb_shared) {
     if (n < 0 || !out_count || (n > 0 && !db) || row_begin < 0 || row_end > n || cap < 0) return HVD_ERR_ARG;
     if (((uintptr_t)db & 7) != 0) return HVD_ERR_ARG;
     if (num_threads < 1) num_threads = 1;
@@ -516,9 +516,9 @@ int hvd_cpu_allpairs_hamming256_rows(const uint8_t* db, int64_t n, const int32_t
     if (num_threads > rows) num_threads = (int)rows;
     pair_job jobs[256];
     pthread_t th[256];
-    uint64_t* tdb = NULL;
+    uint64_t* tdb = tdb_shared;
 #if defined(__x86_64__)
-    if (have_avx512_vpopcnt() && n >= 64) tdb = transpose_blocks((const uint64_t*)db, n / 8);
+    if (!tdb && have_avx512_vpopcnt() && n >= 64) tdb = transpose_blocks((const uint64_t*)db, n / 8);
 #endif
     /* Split rows so that each thread gets ~equal triangle area. */
     double total = 0;
@@ -547,6 +547,43 @@ int hvd_cpu_allpairs_hamming256_rows(const uint8_t* db, int64_t n, const int32_t
         }
         count += jobs[t].count;
         free(jobs[t].out);
+    }
+    if (!tdb_shared) free(tdb);
+    *out_count = count;
+    return count > cap ? HVD_ERR_OVERFLOW : HVD_OK;
+}
+
+int hvd_cpu_allpairs_hamming256_rows(const uint8_t* db, int64_t n, const int32_t* group, int64_t row_begin,
+                                     int64_t row_end, int max_dist, hvd_pair* out, int64_t cap,
+                                     int64_t* out_count, int num_threads) {
+    return allpairs_rows_impl(db, n, group, row_begin, row_end, max_dist, out, cap, out_count, num_threads, NULL);
+}
+
+/* Several row bands of the same brute force in one call (the full-size parity checks sample bands of a DB too large to
+ * scan whole): bands[2k], bands[2k+1] = [row_begin, row_end) of band k, ascending and disjoint, so that the output --
+ * band after band, each sorted by (i, j) -- is sorted as a whole. The block-transposed copy of the DB is built once. */
+int hvd_cpu_allpairs_hamming256_bands(const uint8_t* db, int64_t n, const int32_t* group, const int64_t* bands,
+                                      int64_t n_bands, int max_dist, hvd_pair* out, int64_t cap, int64_t* out_count,
+                                      int num_threads) {
+    if (n < 0 || !out_count || (n > 0 && !db) || n_bands < 0 || (n_bands > 0 && !bands) || cap < 0) return HVD_ERR_ARG;
+    if (((uintptr_t)db & 7) != 0) return HVD_ERR_ARG;
+    for (int64_t k = 0; k < n_bands; ++k)
+        if (bands[2 * k] < (k ? bands[2 * k - 1] : 0) || bands[2 * k + 1] < bands[2 * k] || bands[2 * k + 1] > n) return HVD_ERR_ARG;
+    uint64_t* tdb = NULL;
+#if defined(__x86_64__)
+    if (have_avx512_vpopcnt() && n >= 64) tdb = transpose_blocks((const uint64_t*)db, n / 8);
+#endif
+    int64_t count = 0;
+    for (int64_t k = 0; k < n_bands; ++k) {
+        int64_t c = 0;
+        const int64_t room = cap > count ? cap - count : 0;
+        int rc = allpairs_rows_impl(db, n, group, bands[2 * k], bands[2 * k + 1], max_dist, out + (room ? count : 0), room, &c,
+                                    num_threads, tdb);
+        if (rc != HVD_OK && rc != HVD_ERR_OVERFLOW) {
+            free(tdb);
+            return rc;
+        }
+        count += c;
     }
     free(tdb);
     *out_count = count;

@@ -52,6 +52,9 @@ def lib() -> C.CDLL:
         L.hvd_cpu_allpairs_hamming256_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                                        C.c_int, C.c_void_p, C.c_int64, i64p, C.c_int]
         L.hvd_cpu_allpairs_hamming256_rows.restype = C.c_int
+        L.hvd_cpu_allpairs_hamming256_bands.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                                        C.c_void_p, C.c_int64, i64p, C.c_int]
+        L.hvd_cpu_allpairs_hamming256_bands.restype = C.c_int
         L.hvd_cpu_allpairs_count.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.hvd_cpu_allpairs_count.restype = C.c_int64
         L.hvd_cpu_match_two.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, i32p, i32p]
@@ -123,6 +126,29 @@ def allpairs(db: np.ndarray, max_dist: int = 31, group: np.ndarray | None = None
     res = out[: cnt.value].copy()
     res.sort(order=["i", "j"])
     return res
+
+
+def allpairs_bands(db: np.ndarray, bands, max_dist: int = 31, group: np.ndarray | None = None, cap: int = 1 << 20,
+                   num_threads: int = 1) -> np.ndarray:
+    """The brute force restricted to the rows of `bands` = [(row_begin, row_end), ...] (ascending, disjoint): all (i, j)
+    with i in a band, i < j < n, hamming <= max_dist; sorted by (i, j). One block-transposed copy of the DB serves every
+    band (the full-size checks of DBs too large to scan whole: BASELINE configs[3])."""
+    db = np.ascontiguousarray(db, dtype=np.uint8).reshape(-1, 32)
+    n = db.shape[0]
+    b = np.ascontiguousarray(np.asarray(bands, dtype=np.int64).reshape(-1, 2))
+    if group is not None:
+        group = np.ascontiguousarray(group, dtype=np.int32)
+        assert group.shape == (n,)
+    out = np.zeros(max(cap, 1), dtype=PAIR_DTYPE)
+    cnt = C.c_int64(0)
+    rc = lib().hvd_cpu_allpairs_hamming256_bands(db.ctypes.data, n, group.ctypes.data if group is not None else None,
+                                                 b.ctypes.data, b.shape[0], max_dist, out.ctypes.data, cap, C.byref(cnt),
+                                                 num_threads)
+    if rc == -3:
+        return allpairs_bands(db, b, max_dist, group, cap=int(cnt.value), num_threads=num_threads)
+    if rc != 0:
+        raise RuntimeError(f"oracle allpairs_bands rc={rc}")
+    return out[: cnt.value].copy()
 
 
 def allpairs_count(db: np.ndarray, max_dist: int = 31, num_threads: int = 1, native: bool = False) -> int:

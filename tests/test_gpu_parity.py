@@ -242,9 +242,10 @@ def _run_variant(gpu, hvd, db, variant, max_dist=31, group=None, cap=1 << 16):
     return hvd.multigpu.merge_pairs([d_pairs.to_array(gpu.PAIR_DTYPE, cnt)])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("variant", [0, 1, 8, 9, 12, 13, 18])
 def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
-    """Popcount (0..6) and FP4-MFMA (8..14) forms produce the identical pair list."""
+    """Popcount (0, 1) and FP4-MFMA (8, 9, 12, 18, auto 13) forms produce the identical pair list; the forms pruned in round 6
+    are refused."""
     n = 20000
     db, _ = hvd.synth.hash_db(n, seed=53, plant_fraction=0.01)
     want = oracle.allpairs(db, 31, num_threads=8)
@@ -253,7 +254,19 @@ def test_k2_all_kernel_variants_agree(gpu, hvd, oracle, variant):
     assert np.array_equal(_run_variant(gpu, hvd, db, variant, group=grp), oracle.allpairs(db, 31, group=grp, num_threads=8))
 
 
-@pytest.mark.parametrize("variant", [8, 9, 12, 13, 15, 16, 17, 18, 19])
+def test_k2_pruned_forms_are_refused(gpu, hvd):
+    """Round 6 removed the measured-and-lost forms (popcount 2..6, MFMA 10, 11, 14..17, 19): selecting one is an argument
+    error at the C-ABI, never a silent substitute."""
+    db, _ = hvd.synth.hash_db(3000, seed=54)
+    for variant in (2, 3, 4, 5, 6, 7, 10, 11, 14, 15, 16, 17, 19, 20):
+        with pytest.raises(gpu.HvdError):
+            _run_variant(gpu, hvd, db, variant)
+    lib = gpu.load()
+    for v in (10, 15, 19):
+        assert lib.hvd_debug_set(b"vmatch_variant", v) == gpu.HVD_ERR_ARG
+
+
+@pytest.mark.parametrize("variant", [8, 9, 12, 13, 18])
 @pytest.mark.parametrize("max_dist", [0, 31, 63, 64, 127, 128, 256])
 def test_k2_mfma_threshold_routing(gpu, hvd, oracle, variant, max_dist):
     """dot >= 256-2*max_dist is the popcount predicate for every tolerance, including the ones
@@ -644,7 +657,7 @@ def test_randomized_differential_sweep(gpu, hvd, oracle, seed):
     # host entry (default kernel)
     assert np.array_equal(hvd.allpairs_hamming(db, md, group=grp), want)
     # every device variant
-    for variant in (0, 1, 3, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19):
+    for variant in (0, 1, 8, 9, 12, 13, 18):
         assert np.array_equal(_run_variant(gpu, hvd, db, variant, max_dist=md, group=grp, cap=max(len(want), 16)), want), variant
     # rank split of the default kernel
     world = int(rng.integers(2, 6))

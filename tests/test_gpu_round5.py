@@ -7,8 +7,10 @@ implementation:
 
   configs[2]  1M hashes        every kernel form == the CPU oracle's pair list (AVX-512 scan, a few seconds)
   configs[3]  10M hashes       union of the 8 rank tile sets (auto MFMA form) == integer popcount kernel (variant 1)
-  configs[4]  50k x 64 frames  hvd_vmatch records through form 18 == form 8 (256-bit MFMA, no prefilter, no queue)
-                               == a HOST fold of the frame-pair list the popcount kernel produces with the group filter
+                               == (round 6) the CPU oracle on 40+ sampled row bands
+  configs[4]  50k x 64 frames  (round 6) every one of the 3.2M frames hashed by the CPU oracle: kept hashes + CSR == the
+                               device library's; hvd_vmatch records == host fold of the ORACLE's group-filtered frame pairs
+                               == form 18 == form 8 (256-bit MFMA, no prefilter, no queue)
 
 Semantics: dedup.py:445-502 (pair set), db/vptree.py:29-31 (distance), vpdqpy/vpdqpy.py:49-56 (video counters).
 """
@@ -38,17 +40,22 @@ def test_cfg3_full_pair_list_equals_the_oracle_in_every_form(gpu, hvd, oracle):
     _pairs_equal(hvd.allpairs_hamming(db, 31), want, "hvd_allpairs_hamming256")
     d_db = gpu.DeviceBuffer.from_array(db)
     try:
-        for v in (0, 1, 8, 9, 12, 13, 15, 18):
+        for v in (0, 1, 8, 9, 12, 13, 18):
             got = hvd.multigpu.sharded_allpairs(d_db.ptr, n, 0, 1, None, variant=v)
             _pairs_equal(got, want, f"variant {v}")
     finally:
         d_db.free()
 
 
-def test_cfg4_union_of_8_rank_tile_sets_equals_the_popcount_kernel(gpu, hvd):
+def test_cfg4_union_of_8_rank_tile_sets_equals_the_popcount_kernel_and_the_oracle_row_bands(gpu, hvd, oracle):
     """BASELINE configs[3]: 10M hashes. The 8 ranks' tile sets of the auto FP4-MFMA form, run one after the other on this
-    GPU and merged, equal -- record for record -- the list of the integer popcount kernel (csrc/k_hamming.hip variant 1:
-    xor + v_bcnt, no matrix cores, no FP4 image, different tiling) over the whole triangle in one launch."""
+    GPU and merged, equal -- record for record -- (a) the list of the integer popcount kernel (csrc/k_hamming.hip variant 1:
+    xor + v_bcnt, no matrix cores, no FP4 image, different tiling) over the whole triangle in one launch, and (b) round 6,
+    the CPU ORACLE on sampled row bands: 32 random 2048-row bands, the first and the last rows, and for every rank a band
+    that straddles a row-block boundary whose diagonal tile that rank owns (bench.oracle_check_bands). The oracle scans
+    every column j > i of the 10M for the rows of a band, so a pair lost at ANY tile position of those rows would show."""
+    from bench import oracle_check_bands
+
     n, world = 10_000_000, 8
     db, _ = hvd.synth.hash_db(n, seed=4)
     d_db = gpu.DeviceBuffer.from_array(db)
@@ -63,25 +70,22 @@ def test_cfg4_union_of_8_rank_tile_sets_equals_the_popcount_kernel(gpu, hvd):
     # and the independent list itself verifies on the host
     x = np.unpackbits(db[want["i"]] ^ db[want["j"]], axis=1).sum(1)
     assert np.array_equal(x, want["dist"]) and (want["i"] < want["j"]).all()
+    # (b) the oracle on row bands
+    rows_per_block, _ = hvd.multigpu.tile_geometry(n, 9)
+    bands = oracle_check_bands(n, rows_per_block, world, seed=46)
+    assert len(bands) >= 40 and sum(b - a for a, b in bands) >= 60_000
+    in_band = np.zeros(n, dtype=bool)
+    for a, b in bands:
+        in_band[a:b] = True
+    want_o = oracle.allpairs_bands(db, bands, 31, num_threads=host_threads())
+    assert len(want_o) > 30, "the sampled bands hold too few planted pairs to mean anything"
+    _pairs_equal(got[in_band[got["i"]]], want_o, "8-rank union restricted to the oracle's row bands")
 
 
 def fold_frame_pairs(pairs, video, n_videos):
-    """Host statement of the video-level reduction (vpdqpy/vpdqpy.py:49-56 for every video pair): from frame pairs
-    (i < j, frames of different videos) to one record per video pair a < b with q_hits = distinct frames of a that have
-    a match in b, t_hits = distinct frames of b that have a match in a."""
-    a = video[pairs["i"]].astype(np.int64)
-    b = video[pairs["j"]].astype(np.int64)
-    assert (a < b).all()  # frames are in video order and pairs inside one video were filtered
-    key = a * n_videos + b
-    n_fr = np.int64(video.size)
-    q = np.unique(key * n_fr + pairs["i"].astype(np.int64)) // n_fr
-    t = np.unique(key * n_fr + pairs["j"].astype(np.int64)) // n_fr
-    kq, cq = np.unique(q, return_counts=True)
-    kt, ct = np.unique(t, return_counts=True)
-    assert np.array_equal(kq, kt)
-    out = np.zeros(kq.size, dtype=hvd_vmatch_dtype())
-    out["a"], out["b"], out["q_hits"], out["t_hits"] = kq // n_videos, kq % n_videos, cq, ct
-    return out
+    from bench import fold_frame_pairs as fold
+
+    return fold(pairs, video, n_videos, hvd_vmatch_dtype())
 
 
 def hvd_vmatch_dtype():
@@ -90,11 +94,15 @@ def hvd_vmatch_dtype():
     return _lib.VMATCH_DTYPE
 
 
-def test_cfg5_full_library_records_equal_form8_and_the_host_fold(gpu, hvd):
-    """BASELINE configs[4] search half at full size: 50 000 videos x 64 synthetic frames generated and hashed in HBM.
-    The hvd_vmatch records of the product path (auto -> panel-mark queue, form 18) equal those of form 18 forced, of form
-    8 (full 256-bit MFMA compare: no 128-bit first stage, no survivor queue) and a host fold of the frame-pair list the
-    integer popcount kernel reports under the video group filter."""
+def test_cfg5_full_library_records_equal_the_oracle_form8_and_the_host_fold(gpu, hvd, oracle):
+    """BASELINE configs[4] at full size: 50 000 videos x 64 synthetic frames generated and hashed in HBM.
+    Round 6 -- the CPU ORACLE behind the whole config: all 3.2 M frames are read back and hashed by the oracle; the kept
+    hashes (quality >= 31, db/DedupeDB.py:550-553) and the per-video CSR must equal the device library's byte for byte; the
+    oracle's brute-force scan over all 4.1e12 frame pairs with the video group filter, folded to video-level counters on the
+    host (vpdqpy/vpdqpy.py:49-56), must equal the product's hvd_vmatch records.
+    GPU siblings as before: the records of the product path (auto -> panel-mark queue, form 18) equal those of form 18 forced,
+    of form 8 (full 256-bit MFMA compare: no 128-bit first stage, no survivor queue) and a host fold of the frame-pair list
+    the integer popcount kernel reports under the video group filter."""
     lib = gpu.load()
     V, F = 50_000, 64
     rng = np.random.default_rng(5)
@@ -109,9 +117,29 @@ def test_cfg5_full_library_records_equal_form8_and_the_host_fold(gpu, hvd):
     gpu.check(lib.hvd_dev_synth_video_frames(d_frames.ptr, 0, V, F, 5, d_copy.ptr))
     raw_off = np.arange(V + 1, dtype=np.int64) * F
     _, recs_auto, library = hvd.pipeline.dedupe_frames_on_device(d_frames.ptr, raw_off, 64, 64, 1, keep_library=True)
-    d_frames.free()
-    d_copy.free()
     try:
+        # ---- the oracle over every frame (chunks of 128k frames = 512 MB of host memory at a time)
+        from bench import oracle_hash_device_frames
+
+        ho, qo = oracle_hash_device_frames(gpu, oracle, d_frames.ptr, V * F, host_threads())
+    finally:
+        d_frames.free()
+        d_copy.free()
+    try:
+        keep = qo >= 31
+        kept_o = np.ascontiguousarray(ho[keep])
+        off_o = np.zeros(V + 1, dtype=np.int64)
+        np.cumsum(keep.reshape(V, F).sum(1), out=off_o[1:])
+        assert library.n_frames == kept_o.shape[0] and 2_500_000 < library.n_frames < V * F
+        assert np.array_equal(library.offsets(), off_o), "per-video CSR of the kept frames differs from the oracle's"
+        assert np.array_equal(library.hashes(), kept_o), "kept frame hashes differ from the oracle's"
+        video = library.d_video.to_array(np.int32, library.n_frames)
+        assert np.array_equal(video, np.repeat(np.arange(V, dtype=np.int32), np.diff(off_o)))
+        fp_o = oracle.allpairs(kept_o, 31, group=video, cap=1 << 22, num_threads=host_threads())
+        want_o = fold_frame_pairs(fp_o, video, V)
+        assert len(want_o) >= 900
+        assert np.array_equal(recs_auto, want_o), "video records differ from the fold of the ORACLE's frame pairs"
+
         form = C.c_int(0)
         gpu.check(lib.hvd_debug_get(b"mfma_auto_form", C.byref(form)))
         assert form.value in (9, 12, 18)
@@ -122,16 +150,12 @@ def test_cfg5_full_library_records_equal_form8_and_the_host_fold(gpu, hvd):
                 by_form[v] = library.match_videos()
         finally:
             gpu.check(lib.hvd_debug_set(b"vmatch_variant", 0))
-        assert len(recs_auto) >= 900
         for v, r in by_form.items():
             assert np.array_equal(r, recs_auto), f"form {v} records differ from the product path's (form {form.value})"
-        # the independent path: integer popcount kernel with the group filter -> frame pairs -> host fold
+        # the independent GPU path: integer popcount kernel with the group filter -> frame pairs == the oracle's, pair for pair
         fp = hvd.multigpu.sharded_allpairs(library.d_hashes.ptr, library.n_frames, 0, 1, None, 31,
                                            d_group_ptr=library.d_video.ptr, variant=1, cap=1 << 22)
-        video = library.d_video.to_array(np.int32, library.n_frames)
-        assert (video[fp["i"]] != video[fp["j"]]).all()
-        want = fold_frame_pairs(fp, video, V)
-        assert np.array_equal(recs_auto, want), "video records differ from the host fold of the popcount kernel's frame pairs"
+        _pairs_equal(fp, fp_o, "popcount kernel's frame pairs vs the oracle's")
     finally:
         library.free()
 
@@ -279,7 +303,7 @@ def test_k2_every_form_on_every_first_stage_selection(gpu, hvd, oracle, sel):
     d_db = gpu.DeviceBuffer.from_array(db)
     try:
         _forced_sel(gpu, sel)
-        for v in (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19):
+        for v in (8, 9, 12, 13, 18):
             got = hvd.multigpu.sharded_allpairs(d_db.ptr, n, 0, 1, None, variant=v)
             _pairs_equal(got, want, f"variant {v}, selection {sel}")
         if sel:  # the auto variant reports the forced selection
@@ -456,7 +480,7 @@ def test_video_search_in_a_chosen_bit_order_returns_the_same_records(gpu, hvd, o
         got_x = {}
         for mode in (0, 2, 1):
             gpu.check(lib.hvd_debug_set(b"vmatch_bit_order", mode))
-            for v in (0, 18, 15, 12, 9, 8):
+            for v in (0, 18, 12, 9, 8):
                 gpu.check(lib.hvd_debug_set(b"vmatch_variant", v))
                 assert np.array_equal(hvd.match_videos(fr, off, 31), want), (mode, v)
                 assert used() == (1 if mode == 2 else 0), (mode, used())  # (14 k frames: the automatic mode leaves small libraries alone)

@@ -219,6 +219,48 @@ def test_allpairs_group_filter(oracle):
     assert np.array_equal(got, want)
 
 
+def test_allpairs_bands_equal_the_full_scan_restricted_to_their_rows(oracle):
+    """hvd_cpu_allpairs_hamming256_bands (the checker of the full-size configs[3] test): the rows of several disjoint
+    bands in one call == the golden full list restricted to those rows, with and without the group filter, for any thread
+    count, through the overflow retry; malformed band lists are refused."""
+    g = load_golden("hamming_db.npz")
+    db, full = g["db"], g["pairs"]
+    n = len(db)
+    bands = [(0, 17), (100, 101), (101, 1000), (n - 300, n)]
+    inb = np.zeros(n, dtype=bool)
+    for a, b in bands:
+        inb[a:b] = True
+    want = full[inb[full["i"]]]
+    assert 0 < len(want) < len(full)
+    for threads in (1, 3):
+        assert np.array_equal(oracle.allpairs_bands(db, bands, 31, num_threads=threads), want)
+    assert np.array_equal(oracle.allpairs_bands(db, bands, 31, cap=1), want)  # overflow -> retried with the true size
+    grp = (np.arange(n) // 7).astype(np.int32)
+    wg = want[grp[want["i"]] != grp[want["j"]]]
+    assert np.array_equal(oracle.allpairs_bands(db, bands, 31, group=grp, num_threads=2), wg)
+    assert len(oracle.allpairs_bands(db, [], 31)) == 0
+    assert np.array_equal(oracle.allpairs_bands(db, [(0, n)], 31, num_threads=2), full)
+    for bad in ([(5, 3)], [(0, n + 1)], [(10, 20), (15, 30)]):
+        with pytest.raises(RuntimeError):
+            oracle.allpairs_bands(db, bad, 31)
+
+
+def test_fold_of_group_filtered_frame_pairs_is_the_video_match(oracle):
+    """The full-size configs[4] gate (bench.py / tests/test_gpu_round5.py) derives the expected hvd_vmatch records from the
+    oracle's frame-pair scan with the video group filter, folded on the host. That derivation must itself equal the oracle's
+    direct per-video-pair statement (hvd_cpu_vpdq_match_videos: vpdqpy/vpdqpy.py:49-56 for every pair of videos)."""
+    from bench import fold_frame_pairs
+    from hvd_amd import synth
+
+    fr, off, _ = synth.video_hashes(300, seed=12, frames_per_video=(0, 30), copy_fraction=0.3)
+    V = off.size - 1
+    video = np.repeat(np.arange(V, dtype=np.int32), np.diff(off))
+    fp = oracle.allpairs(fr, 31, group=video, num_threads=2)
+    want = oracle.match_videos(fr, off, 31)
+    assert len(want) > 30
+    assert np.array_equal(fold_frame_pairs(fp, video, V, oracle.VMATCH_DTYPE), want)
+
+
 def test_golden_video_match(oracle):
     g = load_golden("video_match.npz")
     got = oracle.match_videos(g["frames"], g["offsets"], 31)
