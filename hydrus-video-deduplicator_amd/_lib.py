@@ -38,6 +38,7 @@ SIGNATURES = {
     "hvd_get_context": (_int, []),
     "hvd_group_exchange": (_int, []),
     "hvd_group_abort": (_int, []),
+    "hvd_group_rearm": (_int, []),
     "hvd_runtime_info": (_int, [C.c_char_p, _sz]),
     "hvd_shutdown": (_int, []),
     "hvd_last_error": (_int, [C.c_char_p, _sz]),
@@ -196,6 +197,12 @@ def group_exchange() -> str:
 def group_abort() -> None:
     """Release the other contexts' threads from an exchange step this thread will never reach (hvd_group_abort)."""
     load().hvd_group_abort()
+
+
+def group_rearm() -> None:
+    """Put the group back to work after an abandoned exchange (hvd_group_rearm): host barrier re-armed, aborted RCCL
+    communicators re-created. Only while no thread is inside a group call."""
+    check(load().hvd_group_rearm())
 
 
 def runtime_info() -> dict:

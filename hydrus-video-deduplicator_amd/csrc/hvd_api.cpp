@@ -113,6 +113,8 @@ constexpr int kMaxCtx = 16;
 Ctx g_ctx[kMaxCtx];
 int g_nctx = 0;                 // contexts of the group (0 before hvd_init / hvd_init_devices)
 bool g_group_rccl = false;      // the group's contexts hold communicators of one ncclCommInitAll
+bool g_group_was_rccl = false;  // ... did when the group was formed (hvd_group_rearm re-creates aborted communicators)
+thread_local bool t_agreed_exit = false;  // this context left its last group call through an agreement step, in lock-step with its peers
 int g_match_server = 1;         // hvd_debug_set "match_server": hvd_match_two's small operands go to a resident workgroup (1) or to one launch per call (0)
 constexpr unsigned long long kMatchServerIdleUs = 300;  // the server leaves after this long without a call ...
 constexpr unsigned long long kMatchServerLifeUs = 2000;  // ... and after this long in any case (another thread's hipFree / device-wide wait gets its turn)
@@ -348,6 +350,95 @@ int parse_dct_mode(int* out) {
 
 }  // namespace
 
+namespace {
+// The group's communicators are created, aborted and re-created from different threads (hvd_init_devices, hvd_group_abort,
+// hvd_group_rearm, a failing context of run_on_group): one mutex around every transition, and `comm_ready` is claimed under it
+// before ncclCommAbort runs, so that no communicator is aborted twice.
+std::mutex g_comm_mu;
+void abort_group_comms() {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (int k = 0; k < g_nctx; ++k)
+        if (g_ctx[k].comm_ready) {
+            g_ctx[k].comm_ready = false;
+            (void)ncclCommAbort(g_ctx[k].comm);
+        }
+}
+
+// The exchange steps of the sharded searches: RCCL all-gathers between the group's devices (ncclCommInitAll: one process,
+// one communicator per device). RCCL refuses a device that is listed twice -- such a group (a test configuration: two
+// contexts on one GPU) exchanges through host memory instead, and so does a group whose communicators cannot be created;
+// hvd_group_exchange() says which. Also the recovery path of hvd_group_rearm (communicators aborted after a failure).
+void form_group_exchange(bool distinct) {
+    const int n_devices = g_nctx;
+    g_group_rccl = false;
+    if (n_devices <= 1) return;
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    bool rccl = distinct && !getenv("HVD_GROUP_NO_RCCL");
+    if (rccl) {
+        ncclComm_t comms[kMaxCtx];
+        int devices[kMaxCtx];
+        for (int i = 0; i < n_devices; ++i) devices[i] = g_ctx[i].device;
+        ncclResult_t r = ncclCommInitAll(comms, n_devices, devices);
+        const int saved = t_ctx;
+        if (r == ncclSuccess) {
+            for (int i = 0; i < n_devices; ++i) {  // every communicator has an owner first (so that a failure below aborts all)
+                g_ctx[i].comm = comms[i];
+                g_ctx[i].comm_ready = true;
+            }
+            for (int i = 0; i < n_devices && rccl; ++i) {
+                t_ctx = i;
+                (void)hipSetDevice(g.device);
+                g.rank = i;
+                g.world = n_devices;
+                if (!g.x_cnt_in && hipMalloc(&g.x_cnt_in, 16) != hipSuccess) rccl = false;
+                if (!g.x_cnt_all && hipMalloc(&g.x_cnt_all, 16 * (size_t)n_devices) != hipSuccess) rccl = false;
+            }
+        } else {
+            rccl = false;
+        }
+        if (!rccl) {
+            for (int i = 0; i < n_devices; ++i)
+                if (g_ctx[i].comm_ready) {
+                    t_ctx = i;
+                    (void)hipSetDevice(g.device);
+                    free_exchange_buffers();
+                    (void)ncclCommAbort(g.comm);
+                    g.comm_ready = false;
+                }
+            (void)hipGetLastError();
+        }
+        t_ctx = saved;
+    }
+    g_group_rccl = rccl;
+    for (int i = 0; i < n_devices; ++i) {
+        g_ctx[i].host_exchange = !rccl;
+        g_ctx[i].rank = i;
+        g_ctx[i].world = n_devices;
+    }
+}
+
+bool group_devices_distinct() {
+    for (int i = 0; i < g_nctx; ++i)
+        for (int k = 0; k < i; ++k)
+            if (g_ctx[k].device == g_ctx[i].device) return false;
+    return true;
+}
+
+// Put a group whose exchange was abandoned back to work: the host barrier is re-armed; an RCCL group whose communicators were
+// aborted (hvd_group_abort, a hard failure inside a sharded call) gets new ones. Nobody may be inside a group call.
+int rearm_group() {
+    g_hx.rearm();
+    if (g_nctx <= 1 || !g_group_was_rccl) return HVD_OK;
+    bool whole = true;
+    for (int k = 0; k < g_nctx; ++k) whole = whole && g_ctx[k].comm_ready;
+    if (whole) return HVD_OK;
+    abort_group_comms();  // (a half-aborted set: finish the job, then form the group again)
+    form_group_exchange(group_devices_distinct());
+    if (!g_group_rccl) return fail(HVD_ERR_RCCL, "the group's RCCL communicators could not be re-created (exchanging through host memory now)");
+    return HVD_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int hvd_init_devices(const int* devices, int n_devices) {
@@ -357,7 +448,7 @@ int hvd_init_devices(const int* devices, int n_devices) {
     if (g_nctx > 0) {
         bool same = g_nctx == n_devices;
         for (int i = 0; same && i < n_devices; ++i) same = g_ctx[i].device == devices[i];
-        if (same) return HVD_OK;
+        if (same) return rearm_group();  // (idempotent; a group whose exchange was aborted is formed again: include/hvd_mi355x.h)
         return fail(HVD_ERR_STATE, "already bound to %d device(s) starting with device %d; hvd_shutdown() first", g_nctx,
                     g_ctx[0].device);
     }
@@ -383,53 +474,8 @@ int hvd_init_devices(const int* devices, int n_devices) {
     g_group_rccl = false;
     g_hx.words.assign((size_t)n_devices, {});
     g_hx.rearm();
-    if (n_devices > 1) {
-        // The exchange steps of the sharded searches: RCCL all-gathers between the group's devices (ncclCommInitAll: one
-        // process, one communicator per device). RCCL refuses a device that is listed twice -- such a group (a test
-        // configuration: two contexts on one GPU) exchanges through host memory instead, and so does a group whose
-        // communicators cannot be created; hvd_group_exchange() says which.
-        bool rccl = distinct && !getenv("HVD_GROUP_NO_RCCL");
-        if (rccl) {
-            ncclComm_t comms[kMaxCtx];
-            ncclResult_t r = ncclCommInitAll(comms, n_devices, devices);
-            if (r == ncclSuccess) {
-                const int saved = t_ctx;
-                for (int i = 0; i < n_devices; ++i) {  // every communicator has an owner first (so that a failure below aborts all)
-                    g_ctx[i].comm = comms[i];
-                    g_ctx[i].comm_ready = true;
-                }
-                for (int i = 0; i < n_devices && rccl; ++i) {
-                    t_ctx = i;
-                    (void)hipSetDevice(g.device);
-                    g.rank = i;
-                    g.world = n_devices;
-                    if (hipMalloc(&g.x_cnt_in, 16) != hipSuccess || hipMalloc(&g.x_cnt_all, 16 * (size_t)n_devices) != hipSuccess) rccl = false;
-                }
-                t_ctx = saved;
-            } else {
-                rccl = false;
-            }
-            if (!rccl) {
-                const int saved = t_ctx;
-                for (int i = 0; i < n_devices; ++i)
-                    if (g_ctx[i].comm_ready) {
-                        t_ctx = i;
-                        (void)hipSetDevice(g.device);
-                        free_exchange_buffers();
-                        (void)ncclCommAbort(g.comm);
-                        g.comm_ready = false;
-                    }
-                t_ctx = saved;
-                (void)hipGetLastError();
-            }
-        }
-        g_group_rccl = rccl;
-        for (int i = 0; i < n_devices; ++i) {
-            g_ctx[i].host_exchange = !rccl;
-            g_ctx[i].rank = i;
-            g_ctx[i].world = n_devices;
-        }
-    }
+    form_group_exchange(distinct);
+    g_group_was_rccl = g_group_rccl;
     (void)hipSetDevice(g_ctx[0].device);
     return HVD_OK;
 }
@@ -485,13 +531,14 @@ int hvd_group_exchange(void) { return g_nctx <= 1 ? 0 : g_group_rccl ? 1 : 2; }
 
 int hvd_group_abort(void) {
     g_hx.abort();
-    if (g_group_rccl)
-        for (int k = 0; k < g_nctx; ++k)
-            if (g_ctx[k].comm_ready) {
-                g_ctx[k].comm_ready = false;
-                (void)ncclCommAbort(g_ctx[k].comm);
-            }
+    if (g_group_rccl) abort_group_comms();
     return HVD_OK;
+}
+
+int hvd_group_rearm(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_nctx <= 0) return fail(HVD_ERR_STATE, "hvd_group_rearm before hvd_init / hvd_init_devices");
+    return rearm_group();
 }
 
 int hvd_runtime_info(char* buf, size_t len) {
@@ -1058,6 +1105,7 @@ int run_on_group(const std::function<int(int)>& fn) {
     std::once_flag rccl_abort;
     auto body = [&](int i) {
         t_ctx = i;
+        t_agreed_exit = false;
         rc[(size_t)i] = need_ready();
         if (rc[(size_t)i] == HVD_OK) rc[(size_t)i] = fn(i);
         if (rc[(size_t)i] != HVD_OK) {
@@ -1068,15 +1116,12 @@ int run_on_group(const std::function<int(int)>& fn) {
             // releases a peer blocked in a collective on the device; the group then has no exchange until it is
             // initialised again (every later sharded call fails loudly instead of hanging).
             g_hx.abort();
+            // Not when the failure was AGREED: a rank that fails its local phase -- an out-of-memory, the injected
+            // test failure -- reports it through the agreement all-gather, every rank sees it there and all of them return
+            // together: nobody is stranded, and the communicators stay usable for the next call.
             const int code = rc[(size_t)i];
-            if (g_group_rccl && (code == HVD_ERR_HIP || code == HVD_ERR_RCCL || code == HVD_ERR_STATE))
-                std::call_once(rccl_abort, [&] {
-                    for (int k = 0; k < n; ++k)
-                        if (g_ctx[k].comm_ready) {
-                            g_ctx[k].comm_ready = false;
-                            (void)ncclCommAbort(g_ctx[k].comm);
-                        }
-                });
+            if (g_group_rccl && !t_agreed_exit && (code == HVD_ERR_HIP || code == HVD_ERR_RCCL || code == HVD_ERR_STATE))
+                std::call_once(rccl_abort, [&] { abort_group_comms(); });
         }
     };
     std::vector<std::thread> th;
@@ -1642,6 +1687,7 @@ int vmatch_build(const VmArgs& v) {
             }
             for (int r = 0; r < W; ++r)
                 if (words[2 * (size_t)r + 1]) {
+                    t_agreed_exit = true;       // every rank reads the same words and leaves here, in lock-step
                     if (own_rc) return own_rc;  // our own failure: its message is already recorded
                     return fail(HVD_ERR_RCCL, "video search abandoned: rank %d failed %s", r, what);
                 }
@@ -2170,6 +2216,7 @@ int hvd_comm_allgather_pairs(const void* d_pairs, int64_t count, hvd_pair* out_h
     // synchronisation per step instead of two of each (the step of a strong-scaling run at N = 8 is ~2 ms). Only when some
     // rank holds more than kSlot records does a second all-gather move the remainders, padded to the longest; every rank
     // sees the same headers and takes the same branch.
+    static_assert(sizeof(hvd_pair) == 16, "a slot's header (true count, padded) takes the place of one record");
     constexpr size_t kSlot = 1023, kSlotBytes = sizeof(hvd_pair) * (kSlot + 1);
     if (int rc = grow(&g.x_send, &g.x_send_cap, kSlotBytes)) return rc;
     if (int rc = grow(&g.x_recv, &g.x_recv_cap, kSlotBytes * (size_t)W)) return rc;

@@ -127,6 +127,10 @@ def run_on_contexts(fn, world: int | None = None) -> list:
     if world <= 1:
         _lib.set_context(0)
         return [fn(0, 1)]
+    # An earlier call that failed on one rank abandoned the group's exchange to release its peers (below). Nobody is inside a
+    # group call now: re-arm the host barrier / re-create aborted communicators, so that one failure -- a ValueError on every
+    # rank, a KeyboardInterrupt -- does not leave the group dead for the rest of the process.
+    _lib.group_rearm()
     out, err = [None] * world, [None] * world
 
     def body(r):

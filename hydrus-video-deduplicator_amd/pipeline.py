@@ -18,6 +18,7 @@ Two forms:
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -152,19 +153,22 @@ class DeviceLibrary:
             return np.zeros(0, dtype=VMATCH_DTYPE)
         cap = max(4096, self.n_videos) if cap is None else int(cap)
         # the record buffer is kept from call to call (per context): two hipMalloc / hipFree round trips inside every search were
-        # ~1 % of a 50 000-video pass during which the GPU did nothing
-        d_out, d_cnt, _ = _record_buffers(cap)  # (the call is told `cap` as asked, whatever the kept buffer would hold)
-        _lib.check(lib.hvd_dev_vpdq_match_videos(self.image().ptr, self.n_frames, self.d_video.ptr, max_dist,
-                                                 rank, world, d_out.ptr, cap, d_cnt.ptr))
-        cnt = int(d_cnt.to_array(np.uint64, 1)[0])
-        if cnt > cap:  # more video pairs than room: ONLY the emit is repeated (no second O(n^2) pass, no second
-            # key exchange that every rank would have to enter in lock-step)
-            cap = cnt
-            d_out, d_cnt, _ = _record_buffers(cap)
-            _lib.check(lib.hvd_dev_vpdq_emit_again(d_out.ptr, cap, d_cnt.ptr))
+        # ~1 % of a 50 000-video pass during which the GPU did nothing. Buffer, launch and read-back stay under the context's
+        # lock: two threads searching on one context would otherwise read each other's records, or free a buffer the other
+        # is still reading back.
+        with _record_lock():
+            d_out, d_cnt, _ = _record_buffers(cap)  # (the call is told `cap` as asked, whatever the kept buffer would hold)
+            _lib.check(lib.hvd_dev_vpdq_match_videos(self.image().ptr, self.n_frames, self.d_video.ptr, max_dist,
+                                                     rank, world, d_out.ptr, cap, d_cnt.ptr))
             cnt = int(d_cnt.to_array(np.uint64, 1)[0])
-            assert cnt <= cap
-        recs = d_out.to_array(VMATCH_DTYPE, cnt)
+            if cnt > cap:  # more video pairs than room: ONLY the emit is repeated (no second O(n^2) pass, no second
+                # key exchange that every rank would have to enter in lock-step)
+                cap = cnt
+                d_out, d_cnt, _ = _record_buffers(cap)
+                _lib.check(lib.hvd_dev_vpdq_emit_again(d_out.ptr, cap, d_cnt.ptr))
+                cnt = int(d_cnt.to_array(np.uint64, 1)[0])
+                assert cnt <= cap
+            recs = d_out.to_array(VMATCH_DTYPE, cnt)
         # ((a, b) is unique, so the sort need not be stable: numpy's default 64-bit sort is three times faster on 21 k records)
         return recs[np.argsort((recs["a"].astype(np.uint64) << np.uint64(32)) | recs["b"])]
 
@@ -176,9 +180,22 @@ class DeviceLibrary:
 
 
 _RECORD_BUFFERS: dict = {}  # context index -> (d_out, d_cnt, cap): grow-only, released by release_record_buffers()
+_RECORD_LOCKS: dict = {}    # context index -> lock held from the buffer lookup to the end of the read-back
+_RECORD_MU = threading.Lock()
+
+
+def _record_lock():
+    ctx = _lib.load().hvd_get_context()
+    with _RECORD_MU:
+        lk = _RECORD_LOCKS.get(ctx)
+        if lk is None:
+            lk = _RECORD_LOCKS[ctx] = threading.Lock()
+    return lk
+
 
 
 def _record_buffers(cap: int):
+    """(caller holds _record_lock())"""
     ctx = _lib.load().hvd_get_context()
     have = _RECORD_BUFFERS.get(ctx)
     if have is None or have[2] < cap or have[0].ptr is None:
@@ -186,15 +203,17 @@ def _record_buffers(cap: int):
             have[0].free()
             have[1].free()
         have = (DeviceBuffer(16 * cap), DeviceBuffer(8), cap)
-        _RECORD_BUFFERS[ctx] = have
+        with _RECORD_MU:
+            _RECORD_BUFFERS[ctx] = have
     return have
 
 
 def release_record_buffers() -> None:
-    for d_out, d_cnt, _ in _RECORD_BUFFERS.values():
-        d_out.free()
-        d_cnt.free()
-    _RECORD_BUFFERS.clear()
+    with _RECORD_MU:
+        for d_out, d_cnt, _ in _RECORD_BUFFERS.values():
+            d_out.free()
+            d_cnt.free()
+        _RECORD_BUFFERS.clear()
 
 
 def shard_frames(raw_offsets: np.ndarray, world: int) -> int:

@@ -85,7 +85,9 @@ class VpTreeManager:
     # reached shape_vptree since are dropped at the next look).
     # Round 5: the upkeep of the reference's tree is OPT-IN. The tree is out of this build's scope
     #  and the facade's own search never reads it; a database that goes back to the reference's
-    # tree runs the reference's --clear-search-tree once, which rebuilds it from shape_perceptual_hashes.
+    # tree runs the reference's --clear-search-tree once, which rebuilds it from shape_perceptual_hashes. Round 6 (ADVICE
+    # r5): with the upkeep off, every hash that is not in an existing shape_vptree is recorded in hvd_vptree_skipped, so
+    # that the incomplete tree is a detectable state of the database, not a silent one.
     MAX_TREE_WALK = 128
     SKIPPED_TABLE = "hvd_vptree_skipped"
 
@@ -124,9 +126,27 @@ class VpTreeManager:
         perceptual_hash = bytes(perceptual_hash)
         if self._maintain_tree:
             self._insert_into_reference_tree(perceptual_hash_id, perceptual_hash)
+        else:
+            self._mark_left_out_of_reference_tree(perceptual_hash_id)
         if not self._loaded or perceptual_hash_id in self._index:
             return
         self._append(perceptual_hash_id, perceptual_hash)
+
+    def _mark_left_out_of_reference_tree(self, phash_id: int) -> None:
+        """Upkeep of the reference's tree is off (the default): where the database HAS a shape_vptree, record that this hash
+        is not in it (the reference's search walks only shape_vptree, db/vptree.py:664-700, so a database written
+        by this build and opened by the reference again would silently miss the hash). The marker table is what
+        `_check_skipped_marker` reads: a later manager that maintains the tree warns and names the remedy
+        (--clear-search-tree), and the marker empties itself once the rows are in the tree. Databases without the tree
+        tables (never opened by the reference's tree code) are left alone."""
+        try:
+            if self.db.execute("SELECT 1 FROM shape_vptree WHERE phash_id = ?;", (phash_id,)).fetchone() is not None:
+                return
+            self.db.execute(f"CREATE TABLE IF NOT EXISTS {self.SKIPPED_TABLE} ( phash_id INTEGER PRIMARY KEY );")
+            self.db.execute(f"INSERT OR IGNORE INTO {self.SKIPPED_TABLE} ( phash_id ) VALUES ( ? );", (phash_id,))
+        except Exception as exc:  # noqa: BLE001 - sqlite3.OperationalError: no such table (no reference tree on this file)
+            if "no such table" not in str(exc):
+                raise
 
     def _check_skipped_marker(self) -> None:
         """Leaves an earlier manager left out of shape_vptree on this database: still missing -> warn again."""

@@ -39,7 +39,7 @@ extern "C" {
 
 #define HVD_BYTES_PER_PDQ_HASH 32 /* == vpdq.VpdqHash.bytesPerPdqHash, dedup.py:83 */
 #define HVD_UNIQUE_ID_BYTES 128
-#define HVD_ABI_VERSION 5 /* 5 (round 5): + hvd_hasher_acquire_n, hvd_hasher_commit_n, hvd_group_abort, hvd_runtime_info, hvd_timer_mark, hvd_timer_between; 4 (round 4): + hvd_init_devices, hvd_context_count, hvd_set_context, hvd_get_context, hvd_group_exchange; 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
+#define HVD_ABI_VERSION 6 /* 6 (round 6): + hvd_group_rearm; 5 (round 5): + hvd_hasher_acquire_n, hvd_hasher_commit_n, hvd_group_abort, hvd_runtime_info, hvd_timer_mark, hvd_timer_between; 4 (round 4): + hvd_init_devices, hvd_context_count, hvd_set_context, hvd_get_context, hvd_group_exchange; 3 (round 3): + hvd_host_malloc/free, hvd_hasher_set_threads, hvd_dev_vpdq_emit_again, hvd_comm_abort, hvd_dct_matrix_libm */
 /* All-pairs kernel the host entry points use: FP4-MFMA with a 128-bit first stage; which of its two forms runs
  * (survivors fetch their other half | second stage out of registers) is chosen per launch from a probe of the data. */
 #define HVD_DEFAULT_VARIANT 13
@@ -81,9 +81,15 @@ int hvd_group_exchange(void);       /* 0: no group (one context); 1: RCCL betwee
 /* A caller that drives the contexts from its own threads (one per context) and fails on ONE of them before that thread
  * reaches an exchange step calls this so that the others do not wait for it for ever: the host-memory barrier is broken
  * (waiters return HVD_ERR_RCCL), RCCL communicators of the group are aborted (ncclCommAbort releases a collective that is
- * already waiting on the device). The group has no exchange afterwards until hvd_init_devices() forms it again; the
- * library does the same by itself when one context of a host-buffer call fails. */
+ * already waiting on the device). The group has no exchange afterwards until hvd_group_rearm() -- or hvd_init_devices()
+ * with the same device list, which calls it -- forms it again; the library does the same by itself when one context of a
+ * host-buffer call fails hard (a failure every rank left in lock-step through an agreement step aborts nothing). */
 int hvd_group_abort(void);
+/* ABI 6: put a group back to work after an abandoned exchange -- re-arms the host-memory barrier and re-creates RCCL
+ * communicators that were aborted (ncclCommInitAll over the group's devices). Call it when no thread is inside a group call
+ * (hvd_amd.multigpu.run_on_contexts does, before it starts its threads). HVD_OK on a healthy group; HVD_ERR_RCCL if the
+ * communicators cannot be re-created (the group then exchanges through host memory). */
+int hvd_group_rearm(void);
 /* What this process runs on, as one JSON object in buf (NUL-terminated, truncated to len): HIP runtime / driver versions,
  * RCCL version and the path of the librccl that is actually loaded, every visible device (name, PCI bus id, gcnArch, CUs,
  * memory) and the peer matrix of the group's devices (hipDeviceCanAccessPeer, link type and hop count from

@@ -19,7 +19,7 @@ if os.environ.get("CHUNK"): L.check(lib.hvd_debug_set(b"mfma_col_chunk_max", int
 if os.environ.get("LDS_PAD"): L.check(lib.hvd_debug_set(b"mfma_lds_pad", int(os.environ["LDS_PAD"])))
 d_pairs = L.DeviceBuffer(16 * cap); d_cnt = L.DeviceBuffer(8)
 print("kept frames", nk, "comparisons %.3g" % (nk * (nk - 1) / 2))
-for v in [int(x) for x in (sys.argv[1:] or ["12", "14", "8", "13"])]:
+for v in [int(x) for x in (sys.argv[1:] or ["12", "18", "8", "13"])]:
     ks = []
     for r in range(4):
         d_cnt.zero()

@@ -36,7 +36,7 @@ def test_header_symbols_all_exported_and_bound(hvd):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
-    assert lib.hvd_abi_version() == 5
+    assert lib.hvd_abi_version() == 6
 
 
 def test_no_gpu_means_loud_failure_not_fallback(hvd):

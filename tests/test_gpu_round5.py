@@ -252,7 +252,7 @@ def test_copy_nt_switch_is_bit_identical(gpu, hvd):
 
 def test_runtime_info_names_the_device_and_the_libraries(gpu):
     info = gpu.runtime_info()
-    assert info["abi"] == 5 and info["visible_devices"] >= 1
+    assert info["abi"] == 6 and info["visible_devices"] >= 1
     assert "gfx950" in info["devices"][0]["arch"] and info["devices"][0]["cus"] == 256
     assert info["librccl_path"].endswith(".so") or ".so." in info["librccl_path"]
     assert info["rccl_version"] > 20000 and info["hip_runtime_version"] > 0

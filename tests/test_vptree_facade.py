@@ -278,6 +278,21 @@ def test_add_leaf_keeps_the_reference_tree_valid(hvd, oracle):
     conn.execute("INSERT INTO shape_perceptual_hashes VALUES (9999, ?)", (bytes(64),))
     hvd.vptree.VpTreeManager(conn, matcher=m, maintain_reference_tree=False).add_leaf(9999, bytes(64))
     assert 9999 not in _tree_rows(conn)
+    # ... but not silently: the hash is on record as missing from the reference's tree, a manager that maintains
+    # the tree warns about it, and the record empties itself once the reference has rebuilt its tree
+    import warnings
+
+    assert [r[0] for r in conn.execute("SELECT phash_id FROM hvd_vptree_skipped")] == [9999]
+    hvd.vptree.VpTreeManager(conn, matcher=m).add_leaf(5, blobs[4])  # (a hash that IS in the tree leaves no mark)
+    assert conn.execute("SELECT COUNT(*) FROM hvd_vptree_skipped").fetchone()[0] == 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert hvd.vptree.VpTreeManager(conn, matcher=m, maintain_reference_tree=True).tree_incomplete
+        assert any("missing from shape_vptree" in str(x.message) for x in w)
+    conn.execute("INSERT INTO shape_vptree ( phash_id, parent_id, radius, inner_id, inner_population, outer_id, outer_population ) "
+                 "VALUES ( 9999, -1, NULL, NULL, 0, NULL, 0 )")
+    assert not hvd.vptree.VpTreeManager(conn, matcher=m, maintain_reference_tree=True).tree_incomplete
+    assert conn.execute("SELECT COUNT(*) FROM hvd_vptree_skipped").fetchone()[0] == 0
 
 
 def dedupe_keep_order(xs):

@@ -165,35 +165,59 @@ assert np.array_equal(recs_g, recs_1) and np.array_equal(pairs_g, pairs_1) and l
 planted = {(int(min(s, d)), int(max(s, d))) for d, s in enumerate(copy_of) if s >= 0}
 assert planted <= {tuple(p) for p in pairs_g.tolist()}
 
-# ---- a rank that dies BEFORE an exchange step must not strand the others: host-memory groups only -- aborting
-#      an RCCL group drops its communicators, which would end this script's group for good -------------------------------
-if L.group_exchange() == "host":
-    import threading
+# ---- a rank that dies BEFORE an exchange step must not strand the others, and the group must not stay dead
+#      afterwards: run_on_contexts abandons the exchange (host barrier broken / communicators aborted) to release
+#      the peers, and the NEXT run_on_contexts re-arms it (hvd_group_rearm: communicators re-created) -- host and RCCL groups
+import threading
 
-    def dies_early(rank, world):
-        if rank == world - 1:
-            raise ValueError("rank failed before the exchange")
-        d = L.DeviceBuffer(16)
-        d.zero()
+
+def _raises(fn):
+    try:
+        fn()
+    except BaseException as exc:  # noqa: BLE001
+        return exc
+    return None
+
+
+def one_record(rank, world):
+    d = L.DeviceBuffer(16)
+    d.zero()
+    try:
         return M.GroupExchange(rank, world).allgather_pairs_dev(d.ptr, 1)
+    finally:
+        d.free()
 
+
+def dies_early(rank, world):
+    if rank == world - 1:
+        raise ValueError("rank failed before the exchange")
+    return one_record(rank, world)
+
+
+for attempt in range(2):  # (twice: the recovery itself must be repeatable)
     box = {}
     th = threading.Thread(target=lambda: box.setdefault("exc", _raises(lambda: M.run_on_contexts(dies_early))), daemon=True)
-
-    def _raises(fn):
-        try:
-            fn()
-        except BaseException as exc:  # noqa: BLE001
-            return exc
-        return None
-
     th.start()
-    th.join(60)
+    th.join(120)
     assert not th.is_alive(), "the surviving ranks are still waiting for the rank that failed"
     assert isinstance(box["exc"], ValueError), repr(box["exc"])
-    # the next library-driven group call re-arms the barrier: the group works again
+    # a caller that drives the contexts from its own threads gets a working group back ...
+    got = M.run_on_contexts(one_record)
+    assert all(len(g_) == W for g_ in got), [len(g_) for g_ in got]
+    assert L.group_exchange() == ("host" if len(set(devs)) < W else "rccl")
+    # ... and so does the next library-driven group call
     L.set_context(0)
     assert np.array_equal(hvd_amd.allpairs_hamming(db, 31), want)
+
+# a failure every rank leaves in lock-step (the injected local failure of the video search: reported through the agreement
+# all-gather) abandons nothing: the very next sharded search runs on the same communicators, no re-arm in between
+L.check(lib.hvd_debug_set(b"vmatch_fail_rank", W))
+try:
+    exc = _raises(lambda: hvd_amd.match_videos(frames, offsets, 31))
+    assert isinstance(exc, L.HvdError), repr(exc)
+finally:
+    L.check(lib.hvd_debug_set(b"vmatch_fail_rank", 0))
+assert np.array_equal(hvd_amd.match_videos(frames, offsets, 31), wantv)
 
 L.shutdown()
 print("GROUP_OK", devs, "exchange", "host" if len(set(devs)) < W else "rccl")
