@@ -23,9 +23,9 @@
 //   bits     ballot(B > median): lane l, output r is hash bit l + 64 r
 #include <hip/hip_runtime.h>
 
-// HVD_ABL_NOSTATE / HVD_ABL_NOFETCH / HVD_ABL_DMAFETCH builds are timing-only ABLATIONS of the down-sampler that produce
+// HVD_ABL_NOSTATE / HVD_ABL_NOFETCH / HVD_ABL_NOD / HVD_ABL_NOLUMA / HVD_ABL_NOSTATELOAD builds are timing-only ABLATIONS of the down-sampler that produce
 // WRONG RESULTS. They may not come out of the product source with a single -D:
-#if (defined(HVD_ABL_NOSTATE) || defined(HVD_ABL_NOFETCH) || defined(HVD_ABL_DMAFETCH)) && !defined(HVD_DEV_ABLATION)
+#if (defined(HVD_ABL_NOSTATE) || defined(HVD_ABL_NOFETCH) || defined(HVD_ABL_NOD) || defined(HVD_ABL_NOLUMA) || defined(HVD_ABL_NOSTATELOAD)) && !defined(HVD_DEV_ABLATION)
 #error "HVD_ABL_* are developer ablation builds (wrong results): add -DHVD_DEV_ABLATION to confirm"
 #endif
 #include <stdint.h>
@@ -1015,6 +1015,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t idx, f
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(idx * 4u), 0, 0);
 }
 
+
 // soff: wave-uniform byte offset of the unit inside the frame. Instruction i = (NI/2) g + sub covers rows
 // 16 g .. 16 g + 15 (piece u = 64 sub + lane of that 16-row group), so only NI/2 lane-dependent offsets exist;
 // the group offset rides in the scalar offset (loads) or the immediate offset (LDS).
@@ -1103,9 +1104,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
     __shared__ __attribute__((aligned(16))) float buf[kWT * PL];
     static_assert(sizeof(buf) >= 32 * TileLoad<CH>::RS, "the byte staging aliases the transposition buffer");
     __shared__ __attribute__((aligned(16))) uint8_t park[32 * TileLoad<CH>::RS];
-    // this step's C samples [slot % 4][row] alias the transposition buffer: C writes them after its last read of buf
-    float (*smp)[kWR] = reinterpret_cast<float (*)[kWR]>(&buf[0]);
-    static_assert(sizeof(buf) >= 4 * kWR * sizeof(float), "smp aliases buf");
+    // this step's C samples [slot % 4][row] alias the transposition buffer: C writes them after its last read of buf.
+    // Row stride SMPS = 68 dwords, not 64 (round 6): the four lanes that own a step's four sample columns read the same row
+    // index of four different slots in one instruction -- at a stride of 64 dwords those are four addresses in the SAME banks
+    // (a 4-way conflict on every one of pass D's reads: the 17 % conflict cycles of profiles/r04_pmc_down512w.txt); 68 moves each
+    // slot on by four banks, which is what a 128-bit read per lane needs.
+#ifndef HVD_F1_SMPS
+#define HVD_F1_SMPS 68
+#endif
+    constexpr int SMPS = HVD_F1_SMPS;
+    float (*smp)[SMPS] = reinterpret_cast<float (*)[SMPS]>(&buf[0]);
+    static_assert(sizeof(buf) >= 4 * SMPS * sizeof(float) && SMPS >= kWR && SMPS % 4 == 0, "smp aliases buf");
     const uint32_t buf_lds = (uint32_t)(uintptr_t)(&buf[0]);  // LDS byte address of the buffer (M0 base of the addtid stores)
     constexpr int SQ = TileLoad<CH>::SQ;
     static_assert(SQ == NCH * QPC, "a step is NCH chunks of QPC pieces");
@@ -1128,6 +1137,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
         unit_fetch<CH>(r0, 0, lane, pre[0]);
         unit_fetch<CH>(r0, 32 * row_bytes, lane, pre[1]);
     }
+    // (uniform memory schedule, below: in the steady state 34 memory instructions are younger than a unit when it is staged;
+    // behind the two units of the prologue there would be 11 and 20, and the compiler's wait in front of EVERY staging would be
+    // sized for that path. 32 stores that go nowhere -- past the end of the scratch -- make the prologue the longer path.)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) buf_st(rs, (uint32_t)(kWScratchFloats + 64 * i), 0.0f);  // (distinct targets: equal stores would be merged)
     uint4 fifo[SQ];  // the bytes of this lane's row for this step
 #pragma unroll
     for (int q = 0; q < SQ; ++q) fifo[q] = make_uint4(0, 0, 0, 0);
@@ -1135,6 +1149,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
     // (frames strided by the grid; handing them out dynamically, as k_pdq_hash64 does for long launches, was measured:
     // no gain at 6144 frames -- the kernel waits on the memory side -- and a longer tail at sizes that are not a multiple
     // of the resident waves)
+    // UNIFORM MEMORY SCHEDULE (round 6). vmcnt retires in order and hipcc's s_waitcnt bookkeeping takes, for every wait, the
+    // MINIMUM number of younger memory instructions over all paths that reach it. Until round 5 some steps issued the frame
+    // fetch and some did not, stores sat under lane conditions, and the first state load of a tile row stood in front of the
+    // step loop -- so the minimum was 0 and every step began with s_waitcnt vmcnt(0): the frame fetch issued one step earlier
+    // (wanted two steps later) and the acknowledgements of the step's stores were waited for on the spot (ablations in
+    // profiles/r06_down512w_ablation.txt: no state loads -3.6 %, no state traffic -11 %, no D stores -11 %). Now EVERY step issues
+    // the same sequence -- 5 state loads, the fetch slot's loads (one unit into pre[step parity]: a zero-byte resource where
+    // there is nothing to fetch), 5 state stores, 4 output stores (lanes with nothing to store aim past the end of their
+    // resource) -- so the compiler's counts are exact and a wait leaves everything younger than what it needs in flight.
+    float nxB = 0.0f, nxl[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the lower half's pass-B state for the NEXT step, in flight
     for (long long f = blockIdx.x; f < n; f += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rd = make_rsrc(out64 + (size_t)f * 4096, 4096 * sizeof(float));
         float sD = 0.0f, dl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1146,16 +1170,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
             // pass-B state a lane starts its step with: the upper half gets it from the lower half's previous step (a
             // 32-lane shuffle at the end of B), the lower half from the tile row above (loaded at the top of the step)
             float inB = 0.0f, inl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            float nxB = 0.0f, nxl[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the lower half's state for the NEXT step, in flight
-            {  // column tile 0 of this tile row. Loads are UNCONDITIONAL and land in the registers that carry them to their
-               // use: an index past the end of the scratch resource reads 0 and touches no memory (buffer range check),
-               // which is the state of a line's start. A load under a branch, merged with a zero from the other path,
-               // made the compiler copy the result right behind the load -- i.e. wait for it on the spot.
-                const uint32_t p0 = (ty > 0 ? 0u : (uint32_t)kWScratchFloats) + (uint32_t)cl5;
-                nxB = buf_ld(rs, p0);
-                nxl[0] = buf_ld(rs, p0 + 32u); nxl[1] = buf_ld(rs, p0 + 64u);
-                nxl[2] = buf_ld(rs, p0 + 96u); nxl[3] = buf_ld(rs, p0 + 128u);
-            }
+            // (the lower half's state for the NEXT step, nxB / nxl, is in flight from the previous step -- for column tile 0
+            // from the last step of the tile row above: see the load below; a frame starts from zeros)
             const uint32_t rbase = (uint32_t)(kWR * ty) * row_bytes;  // byte offset of the tile row in the frame
 
 #pragma unroll 1
@@ -1175,72 +1191,72 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                         inl[0] = nxl[0]; inl[1] = nxl[1]; inl[2] = nxl[2]; inl[3] = nxl[3];
                     }
                     // unconditional, all lanes (the upper half's copies are never read): see the tile row's first load
+                    // next step = column tile tx + 1 of this tile row (its state was left by the tile row above), or -- from the
+                    // tile row's last step -- column tile 0 of the next tile row (left by this one, 16 steps ago)
 #ifdef HVD_ABL_NOSTATE
                     const bool have = false;
 #else
-                    const bool have = ty > 0 && tx + 1 <= kWNX;
+                    const bool have = tx <= kWNX ? (ty > 0 && tx + 1 <= kWNX) : (ty < kWNY);
 #endif
-                    const uint32_t pi = (have ? (uint32_t)(tx + 1) * (5 * 32) : (uint32_t)kWScratchFloats) + (uint32_t)cl5;
+                    const uint32_t pi = (have ? (uint32_t)(tx <= kWNX ? tx + 1 : 0) * (5 * 32) : (uint32_t)kWScratchFloats) + (uint32_t)cl5;
+#ifdef HVD_ABL_NOSTATELOAD  // timing ablation only (wrong results): no state load at all -> no vmcnt wait at the top of a step
+                    (void)pi;
+                    nxB = 0.0f; nxl[0] = nxl[1] = nxl[2] = nxl[3] = 0.0f;
+#else
                     nxB = buf_ld(rs, pi);
                     nxl[0] = buf_ld(rs, pi + 32); nxl[1] = buf_ld(rs, pi + 64);
                     nxl[2] = buf_ld(rs, pi + 96); nxl[3] = buf_ld(rs, pi + 128);
+#endif
                 }
                 // ---------------- A: luma + rep-1 along the row (lane = row 64ty + lane) -----------------
+                // unit m of half `par` arrives in this step (lower half: steps 2m, 2m+1 <-> tiles 2m, 2m+1; upper half: steps
+                // 2m+1, 2m+2); the other half moves on to the second step of its unit
+                const int hr = par;
+                const bool stage_now = ty < kWNY && tx < kWNX;
+                if (ty < kWNY && tx <= kWNX) {
+                    if (half != hr) {  // second step of this half's unit: parked one step ago
+#pragma unroll
+                        for (int q = 0; q < SQ; ++q)
+                            fifo[q] = *reinterpret_cast<const uint4*>(park + cl5 * TileLoad<CH>::RS + q * 16);
+                    }
+                    wave_mem_sync();  // ... before the arriving unit is parked there
+                    if (stage_now) unit_stage<CH>(stage, park, lane, pre[par]);
+                }
+                {   // THE FETCH SLOT: every step issues the six loads of one unit into pre[par] (uniform memory schedule, above) --
+                    // ONE load site whose frame, offset and SIZE are scalar choices (alternative load sites merged into pre[par]
+                    // made the compiler load into temporaries and copy them over at the join, behind an s_waitcnt vmcnt(0)).
+                    //   steps 0 .. 13 of a tile row: this half's next unit, staged two steps from now
+                    //   steps 14, 15: nothing (a zero-byte resource answers zeros and fetches nothing; pre[par] is dead here)
+                    //   steps 16, 17: this half's first unit of the next tile row -- from the tail tile row: of the next frame --
+                    //                 again two steps ahead of its use (until round 5 it was fetched at steps 14, 15, and the two
+                    //                 tail steps issued nothing: their waits then counted no fetch in flight, see above)
+                    long long fsel = f;
+                    uint32_t fbytes = 0, soff = 0;
+                    if (ty < kWNY) {
+                        if (tx + 2 < kWNX) {
+                            fbytes = frame_bytes;
+                            soff = rbase + (uint32_t)(32 * par) * row_bytes + (uint32_t)((tx + 2 - par) >> 1) * (2 * kWT * CH);
+                        } else if (tx >= kWNX && ty + 1 < kWNY) {
+                            fbytes = frame_bytes;
+                            soff = rbase + (uint32_t)(kWR + 32 * par) * row_bytes;
+                        }
+                    } else if (tx >= kWNX && f + gridDim.x < n) {
+                        fsel = f + gridDim.x;
+                        fbytes = frame_bytes;
+                        soff = (uint32_t)(32 * par) * row_bytes;
+                    }
+#ifdef HVD_ABL_NOFETCH  // timing ablation only: every prefetch reads from a zero-byte resource
+                    fbytes = 0;
+#endif
+                    unit_fetch<CH>(make_rsrc(frames + (size_t)fsel * frame_bytes, fbytes), soff, lane, pre[par]);
+                }
                 if (ty < kWNY) {
                     float tailA = 0.0f;
                     if (tx >= kWNX) {  // phase 4: output 510 = (sum - x[508]) / 3; output 511 is never sampled
                         tailA = __fmul_rn(__fdiv_rn(__fsub_rn(sA, al[0]), 3.0f), 4.0f);
                     }
                     if (tx <= kWNX) {
-                        // unit m of half `par` arrives in this step (lower half: steps 2m, 2m+1 <-> tiles 2m, 2m+1;
-                        // upper half: steps 2m+1, 2m+2); the other half moves on to the second step of its unit
-                        const int hr = par;
-                        if (half != hr) {  // second step of this half's unit: parked one step ago
-#pragma unroll
-                            for (int q = 0; q < SQ; ++q)
-                                fifo[q] = *reinterpret_cast<const uint4*>(park + cl5 * TileLoad<CH>::RS + q * 16);
-                        }
-                        wave_mem_sync();  // ... before the arriving unit is parked there
-                        if (tx < kWNX) {
-                            unit_stage<CH>(stage, park, lane, pre[par]);
-                            // this half's next unit (needed two steps from now, or in the next tile row / frame): ONE load
-                            // site whose frame and offset are scalar choices. Three alternative load sites merged into
-                            // pre[par] made the compiler load into temporaries and copy them over at the join -- behind an
-                            // s_waitcnt vmcnt(0), i.e. every "prefetch" was waited for the moment it was issued.
-                            long long fsel = f;
-                            uint32_t fbytes = frame_bytes, soff;
-                            if (tx + 2 < kWNX) {
-                                soff = rbase + (uint32_t)(32 * par) * row_bytes + (uint32_t)((tx + 2 - par) >> 1) * (2 * kWT * CH);
-                            } else if (ty + 1 < kWNY) {
-                                soff = rbase + (uint32_t)(kWR + 32 * par) * row_bytes;
-                            } else if (f + gridDim.x < n) {
-                                fsel = f + gridDim.x;
-                                soff = (uint32_t)(32 * par) * row_bytes;
-                            } else {  // nothing left: a resource of zero bytes returns zeros and fetches nothing
-                                fbytes = 0;
-                                soff = 0;
-                            }
-#ifdef HVD_ABL_NOFETCH  // timing ablation only: every prefetch reads from a zero-byte resource
-                            fbytes = 0;
-#endif
-#ifdef HVD_ABL_DMAFETCH  // timing ablation only (round 4, results wrong): the frame arrives through LDS-DMA instead -- whole
-                         // 128-byte lines, every byte requested exactly once: for every SECOND unit of a half, 32 rows x 384
-                         // bytes as 12 global_load_lds of 1 KB -- and the register fetch reads from a zero-byte resource.
-                         // Asks: is a duplicate-free, line-aligned DMA fetch (the structure VERDICT r3 next-3 proposes) worth
-                         // building? All instructions target one scratch KB of LDS; vmcnt waits fall where the real ones do.
-                            if (fbytes != 0 && CH == 3 && (((soff % row_bytes) / (2 * kWT * CH)) & 1u) == 0u) {
-                                const uint8_t* strip = frames + (size_t)fsel * frame_bytes + soff;
-#pragma unroll
-                                for (int i = 0; i < 12; ++i) {
-                                    const uint32_t piece = 64u * (uint32_t)i + (uint32_t)lane;
-                                    const uint8_t* src = strip + (size_t)(piece / 24u) * row_bytes + (piece % 24u) * 16u;
-                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                                     (__attribute__((address_space(3))) void*)park, 16, 0, 0);
-                                }
-                            }
-                            fbytes = 0;
-#endif
-                            unit_fetch<CH>(make_rsrc(frames + (size_t)fsel * frame_bytes, fbytes), soff, lane, pre[par]);
+                        if (stage_now) {
                             wave_mem_sync();
                             if (half == hr) {
 #pragma unroll
@@ -1259,6 +1275,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
 #pragma unroll
                         for (int j = 0; j < kWT / 4; ++j) {
                             float v[4];
+#ifdef HVD_ABL_NOLUMA  // timing ablation only (wrong results): one conversion per pixel instead of the 8-instruction luma
+                            if (CH == 3) {
+                                const uint32_t w0 = fifo_word(fifo, 3 * j), w1 = fifo_word(fifo, 3 * j + 1), w2 = fifo_word(fifo, 3 * j + 2);
+                                v[0] = (float)(w0 & 0xFFu); v[1] = (float)(w0 >> 24); v[2] = (float)((w1 >> 16) & 0xFFu); v[3] = (float)((w2 >> 8) & 0xFFu);
+                            } else
+#endif
                             if (CH == 3) {
                                 const uint32_t w0 = fifo_word(fifo, 3 * j), w1 = fifo_word(fifo, 3 * j + 1), w2 = fifo_word(fifo, 3 * j + 2);
                                 v[0] = luma_rgb_f((float)(w0 & 0xFFu), (float)((w0 >> 8) & 0xFFu), (float)((w0 >> 16) & 0xFFu));
@@ -1302,6 +1324,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                 {
                     const bool valid = (txl == 0) ? (cl5 >= 2) : (txl == kWNX) ? (cl5 == 0) : (txl > 0 && txl < kWNX);
                     const uint32_t sti = (uint32_t)(txl < 0 ? 0 : txl) * (5 * 32) + (uint32_t)cl5;  // index into the state scratch
+                    float stS = 0.0f, stl[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // what the upper half leaves for the tile row below
+                    bool st_ok = false;
                     if (ty < kWNY) {
                         float sB = inB, bl[4] = {inl[0], inl[1], inl[2], inl[3]};
                         // my column (cl5), my half's 32 rows: one contiguous run of the column-major buffer
@@ -1342,15 +1366,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                         }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) bl[k] = x[28 + k];
-#ifdef HVD_ABL_NOSTATE
-                        if (false) {
-#else
-                        if (half && valid) {
+                        stS = sB;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) stl[k] = bl[k];
+#ifndef HVD_ABL_NOSTATE
+                        st_ok = half && valid;
 #endif
-                            buf_st(rs, sti, sB);
-                            buf_st(rs, sti + 32, bl[0]); buf_st(rs, sti + 64, bl[1]);
-                            buf_st(rs, sti + 96, bl[2]); buf_st(rs, sti + 128, bl[3]);
-                        }
                         // lower half -> upper half of the next step (lane l -> lane l + 32)
                         inB = __shfl_up(sB, 32, 64);
 #pragma unroll
@@ -1358,6 +1379,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                     } else if (half == 0 && valid) {  // phase 4, row 510 only (buffer row 0)
                         const float sB = __fsub_rn(inB, inl[0]);
                         lds_store1_addtid<0>(buf_lds, __fmul_rn(__fdiv_rn(sB, 3.0f), 4.0f));  // row-major element (row 0, column cl5 = lane)
+                    }
+                    {  // every step, every lane (uniform memory schedule): lanes with nothing to leave aim past the scratch's end
+                        const uint32_t si = st_ok ? sti : (uint32_t)kWScratchFloats;
+                        buf_st(rs, si, stS);
+                        buf_st(rs, si + 32, stl[0]); buf_st(rs, si + 64, stl[1]);
+                        buf_st(rs, si + 96, stl[2]); buf_st(rs, si + 128, stl[3]);
                     }
                 }
                 wave_mem_sync();
@@ -1400,7 +1427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                     }
                     wave_mem_sync();  // every lane has read its buffer row; the samples may now overwrite it
                     if (store) {  // smp[k][lane]: lane-contiguous, 256 bytes per slot
-                        lds_store4_addtid<0, kWR * 4>(buf_lds, sv[0], sv[1], sv[2], sv[3]);
+                        lds_store4_addtid<0, SMPS * 4>(buf_lds, sv[0], sv[1], sv[2], sv[3]);
                     } else if (tail) {
                         lds_store1_addtid<0>(buf_lds, sv[0]);
                     }
@@ -1417,7 +1444,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                 // i = 8ty-1+r/8 iff r % 8 == 0.
                 {
                     const int js = lane + 1, gs = js >> 2;
+#ifdef HVD_ABL_NOD  // timing ablation only (wrong results): pass D does nothing
+                    const bool lo_pass = false, hi_pass = false;
+#else
                     const bool lo_pass = (gs == tx) && (tx <= kWNX), hi_pass = (gs == tx - 1);
+#endif
+                    // the step's (up to) four outputs of a lane and where they go; 4096 = past the end of the frame's 64 x 64
+                    // floats = nowhere (every step issues its four stores: uniform memory schedule)
+                    uint32_t di[4] = {4096u, 4096u, 4096u, 4096u};
+                    float dv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (lo_pass || hi_pass) {
                         const int r0 = hi_pass ? 32 : 0;
                         const float* zp = &smp[js & 3][r0];
@@ -1432,14 +1467,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH == 3 ? 3 
                                 }
                                 w_run<kWC>(sD, dl, z, o);
                                 const int ib = 8 * ty - 1 + ((r0 + kWC * k) >> 3);
-                                if (ib >= 0) buf_st(rd, (uint32_t)(ib * 64 + lane), __fmul_rn(o[0], 0x1p-8f));
-                                buf_st(rd, (uint32_t)((ib + 1) * 64 + lane), __fmul_rn(o[8], 0x1p-8f));
+                                if (ib >= 0) di[2 * k] = (uint32_t)(ib * 64 + lane);
+                                dv[2 * k] = __fmul_rn(o[0], 0x1p-8f);
+                                di[2 * k + 1] = (uint32_t)((ib + 1) * 64 + lane);
+                                dv[2 * k + 1] = __fmul_rn(o[8], 0x1p-8f);
                             }
                         } else if (lo_pass) {  // Y = 510 (row 0 of the tail tile row): output 508 = decimation row 63
                             sD = __fsub_rn(__fadd_rn(sD, zp[0]), dl[0]);
-                            buf_st(rd, (uint32_t)(63 * 64 + lane), __fmul_rn(sD, 0x1p-8f));
+                            di[0] = (uint32_t)(63 * 64 + lane);
+                            dv[0] = __fmul_rn(sD, 0x1p-8f);
                         }
                     }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) buf_st(rd, di[i], dv[i]);
                 }
                 wave_mem_sync();  // smp is rewritten by the next step
             }

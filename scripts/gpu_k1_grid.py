@@ -7,7 +7,7 @@ fr = synth.frames_gray(10000, seed=2)
 d_f = L.DeviceBuffer.from_array(fr); d_h, d_q = L.DeviceBuffer(32 * 10000), L.DeviceBuffer(4 * 10000)
 for src in (0, 2):
     L.check(lib.hvd_debug_set(b"pdq_dct_from_lds", src))
-    for grid in (0, 2500, 1792, 1280, 1250, 1024, 834, 768, 625, 512):
+    for grid in (0, 2500, 2304, 2048, 1792, 1536, 1280, 1250, 1024, 834):
         L.check(lib.hvd_debug_set(b"pdq_hash_grid", grid))
         ks = []
         for r in range(30):
