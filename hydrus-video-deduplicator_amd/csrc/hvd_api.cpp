@@ -26,6 +26,7 @@
 #include <thread>
 #include <vector>
 
+#include "host_barrier.h"
 #include "hvd_kernels.h"
 #include "../../include/hvd_mi355x_bench.h"
 
@@ -122,43 +123,9 @@ thread_local int t_ctx = 0;     // the calling thread's current context
 #define g (g_ctx[t_ctx])
 std::mutex g_mu;
 
-// Rendezvous of the group's worker threads (one per context) for the exchange steps that have no RCCL underneath: a group
-// that lists one device twice (RCCL refuses duplicate devices; tests/test_gpu_round4.py), where the ranks' candidates and
-// keys meet in host memory instead. A plain generation barrier plus a slot per rank.
-// The barrier can be ABORTED: a rank that leaves a group call with an error -- a HIP failure between two
-// barriers, a context that is not ready -- breaks it (run_on_group), so that its peers come out of their wait with `false`
-// and return an error instead of waiting for ever with the group mutex held. run_on_group re-arms it for the next call.
-struct HostExchange {
-    std::mutex mu;
-    std::condition_variable cv;
-    int arrived = 0;
-    unsigned long long gen = 0;
-    bool broken = false;
-    std::vector<std::vector<unsigned long long>> words;  // one vector per rank
-    bool barrier(int n) {
-        std::unique_lock<std::mutex> lk(mu);
-        if (broken) return false;
-        const unsigned long long my = gen;
-        if (++arrived == n) {
-            arrived = 0;
-            ++gen;
-            cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return gen != my || broken; });
-        }
-        return gen != my;  // (completed: true even if a rank that left through it has broken it since)
-    }
-    void abort() {
-        std::lock_guard<std::mutex> lk(mu);
-        broken = true;
-        cv.notify_all();
-    }
-    void rearm() {
-        std::lock_guard<std::mutex> lk(mu);
-        broken = false;
-        arrived = 0;
-    }
-};
+// Rendezvous of the group's worker threads for the exchange steps that have no RCCL underneath: csrc/host_barrier.h (abortable
+// generation barrier + a slot of words per rank; TSan-tested on the CPU).
+using hvd::HostExchange;
 HostExchange g_hx;
 // every host-memory barrier of a group call: a broken barrier ends the call on this rank too
 #define HX_BARRIER(W)                                                                                              \
@@ -166,13 +133,8 @@ HostExchange g_hx;
         if (!g_hx.barrier(W)) return fail(HVD_ERR_RCCL, "group exchange abandoned: another context of the group failed"); \
     } while (0)
 
-// Declared at the top of every host-memory exchange block: whoever leaves the block early (HIP_TRY, a broken barrier)
-// breaks the barrier for its peers on the way out; the normal exit -- after the block's last barrier -- disarms it.
-struct HxGuard {
-    bool done = false;
-    ~HxGuard() {
-        if (!done) g_hx.abort();
-    }
+struct HxGuard : hvd::HxGuard {  // (host_barrier.h; bound to the group's one exchange)
+    HxGuard() : hvd::HxGuard(g_hx) {}
 };
 
 // pdqhashing.cpp fill_dct_matrix_64_cached: float scale * double cos, rounded once.
@@ -209,8 +171,10 @@ bool pair_less(const hvd_pair& x, const hvd_pair& y) { return x.i != y.i ? x.i <
 
 }  // namespace
 
+extern "C" {  // (defined further down inside the extern "C" block: g++ insists that declaration and definition agree)
 static void free_exchange_buffers();
 static int grow(void** p, size_t* cap, size_t need);
+}
 
 namespace hvd {
 int api_fail(int code, const char* fmt, ...) {

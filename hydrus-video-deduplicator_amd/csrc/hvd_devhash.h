@@ -23,6 +23,7 @@ __host__ __device__ __forceinline__ uint32_t vkey_side(unsigned long long k) { r
 __host__ __device__ __forceinline__ uint32_t vkey_frame(unsigned long long k) { return (uint32_t)(k >> 31); }
 __host__ __device__ __forceinline__ uint32_t vkey_video(unsigned long long k) { return (uint32_t)(k & 0x7FFFFFFFull); }
 
+#if defined(__HIPCC__)  // device code below: the host layer also builds with a plain C++ compiler (make asan: g++ + ASan / UBSan)
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     x ^= x >> 33;
     x *= 0xff51afd7ed558ccdull;
@@ -55,6 +56,8 @@ __device__ __forceinline__ unsigned long long table_insert(unsigned long long* _
     return ~0ull;
 }
 
+#endif  // __HIPCC__
+
 // What the all-pairs kernel needs to reduce to video level instead of appending frame pairs.
 struct VideoSink {
     unsigned long long* set;       // nullptr => frame-pair mode
@@ -64,6 +67,7 @@ struct VideoSink {
     const int32_t* vid_t;          // video index of every column frame (== vid_q in the symmetric form)
 };
 
+#if defined(__HIPCC__)
 __device__ __forceinline__ void sink_insert(const VideoSink& vs, unsigned long long key) {
     bool is_new;
     const unsigned long long slot = table_insert(vs.set, vs.mask, key, &is_new);
@@ -72,5 +76,6 @@ __device__ __forceinline__ void sink_insert(const VideoSink& vs, unsigned long l
     else if (is_new)
         atomicAdd(&vs.counters[1], 1ull);
 }
+#endif  // __HIPCC__
 
 }  // namespace hvd
