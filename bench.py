@@ -288,6 +288,22 @@ def load_traffic(key):
         return None
 
 
+def traffic_provenance():
+    """Is profiles/hbm_traffic.json still about THESE kernels? The file records the sha256 of the kernel sources it was measured
+    on (scripts/make_hbm_traffic.py); a kernel file that has changed since makes every `traffic` of this line stale."""
+    import hashlib
+
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        want = rec.get("_kernel_sources_sha256") or {}
+        csrc = os.path.join(ROOT, "hydrus-video-deduplicator_amd", "csrc")
+        changed = sorted(f for f, h in want.items()
+                         if hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] != h)
+        return {"measured_in": rec.get("_round"), "kernel_sources_changed_since": changed, "stale": bool(changed) or not want}
+    except Exception as exc:  # noqa: BLE001
+        return {"stale": True, "error": repr(exc)}
+
+
 def videohasher_stream_leg(lib, L, synth, vpdq):
     """The reference's actual hashing call pattern (vpdqpy/vpdqpy.py:113-119): ONE VideoHasher per video, one
     hash_frame(...) per frame, finish() per video, videos strictly one after the other -- through the drop-in Python
@@ -1047,6 +1063,24 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             "cfg4": "`value`: all-pairs comparisons/s over BASELINE configs[3] (10M hashes, fixed total work) at every N",
         }[args.mode],
     }
+    if world > 1:
+        # what this line is to be held against: the step time predicted from the N = 1 measurements and the
+        # exact tile partition (hvd_amd.multigpu.SCALING_MODEL / predict_step; table in DESIGN.md section 5)
+        try:
+            pred = M.predict_step(n, world)
+            pred1 = M.predict_step(args.hashes, 1)
+            pred["efficiency"] = round(pred["comparisons_per_s"] / (world * pred1["comparisons_per_s"]), 3)
+            pred["basis"] = ("N = 1 measurements of round 6 (kernel 3.62 ms per 1e11 comparisons, fixed per-step pieces) + the exact "
+                             "work share of the slowest rank; not fitted to any multi-GPU run")
+            pred["measured_over_predicted"] = round(ms_per_step / pred["ms_per_step"], 3)
+            out["predicted"] = pred
+            if strong:
+                ps = M.predict_step(args.hashes, world)
+                ps["efficiency"] = round(ps["comparisons_per_s"] / (world * pred1["comparisons_per_s"]), 3)
+                ps["measured_over_predicted"] = round(strong["ms_per_step"] / ps["ms_per_step"], 3)
+                strong["predicted"] = ps
+        except Exception as exc:  # noqa: BLE001 - a diagnostics block must not be able to take the measurement with it
+            out["predicted"] = {"error": repr(exc)}
     if strong:
         out["strong"] = strong
     if cfg4:
@@ -1433,6 +1467,7 @@ def rank_main(args, rank, local_rank, world, real_stdout, inproc):
             runtime.setdefault("telemetry_unmatched", []).append(tel)
     out["runtime"] = runtime
     out["policies"] = policies
+    out["traffic_provenance"] = traffic_provenance()
     if cpu:
         out["cpu_baseline"] = cpu
         out["full_size_oracle_check"] = cpu["full_size_oracle_check"]

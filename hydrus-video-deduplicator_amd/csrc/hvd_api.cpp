@@ -712,11 +712,6 @@ int hvd_debug_set(const char* key, int value) {
         hvd::g_pdq_luma_lut = value;
         return HVD_OK;
     }
-    if (strcmp(key, "fp4_code") == 0) {
-        if (value != 1 && value != 2 && value != 4 && value != 6) return fail(HVD_ERR_ARG, "fp4_code must be 1, 2, 4 or 6");
-        hvd::g_fp4_code = (uint32_t)value;
-        return HVD_OK;
-    }
     if (strcmp(key, "mfma_col_chunk_max") == 0) {
         if (value < 256 || value % 128) return fail(HVD_ERR_ARG, "mfma_col_chunk_max must be a multiple of 128, >= 256");
         hvd::g_mfma_col_chunk_max = (uint32_t)value;
@@ -730,11 +725,6 @@ int hvd_debug_set(const char* key, int value) {
     if (strcmp(key, "mfma_force_sel") == 0) {  // which 128 bits the first stage sees: -1 the probe's choice, 0 bits 0..127, 1 bits 128..255, 2 bits 0..63 + 192..255
         if (value < -1 || value > 2) return fail(HVD_ERR_ARG, "mfma_force_sel: -1 (the probe chooses) or 0 | 1 | 2");
         hvd::g_mfma_force_sel = value;
-        return HVD_OK;
-    }
-    if (strcmp(key, "mfma_lds_pad") == 0) {  // occupancy experiments: bytes of unused dynamic LDS per workgroup of the FP4-MFMA kernels
-        if (value < 0 || value > 65536) return fail(HVD_ERR_ARG, "mfma_lds_pad: 0..65536 bytes");
-        hvd::g_mfma_lds_pad = (uint32_t)value;
         return HVD_OK;
     }
     if (strcmp(key, "mfma_queue_packed") == 0) {  // 0: the pair-queue form settles its candidates from the FP4 images only

@@ -36,9 +36,8 @@ bool allpairs_geometry(uint32_t n, int variant, uint32_t* rows_per_block, uint32
 // FP4-MFMA forms (k_hamming_mfma.hip), variants 8, 9, 12, 13 (auto), 18. d_img: fp4_rows_padded(n)*128 bytes.
 uint32_t fp4_rows_padded(uint32_t n);
 extern uint32_t g_mfma_col_chunk_max;
-extern uint32_t g_mfma_auto_mid, g_mfma_auto_mid_max_x100, g_mfma_queue_packed, g_mfma_lds_pad;
+extern uint32_t g_mfma_auto_mid, g_mfma_auto_mid_max_x100, g_mfma_queue_packed;
 extern int g_mfma_force_sel;
-extern uint32_t g_fp4_code;
 hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s);
 hipError_t launch_pack_fp4(const void* d_img, uint32_t n, void* d_db, hipStream_t s);  // image -> packed 32-byte hashes
 // data-dependent bit order of the video search (k_hamming_mfma.hip): co-occurrence counts of a strided sample, and the rewrite

@@ -11,7 +11,7 @@
 // 32x32 block of comparisons over 64 bits in one instruction (32 cycles/SIMD), against
 // 16 half-rate VALU ops per comparison for the popcount form.
 //
-// Data: k_expand_fp4 writes the "FP4 image" of the DB once: 128 B per hash = 8 chunks of
+// Data (k_fp4_image.hip, hvd_fp4.h): k_expand_fp4 writes the "FP4 image" of the DB once: 128 B per hash = 8 chunks of
 // 16 B (chunk c = bits 32c..32c+31 as 32 nibbles); chunk c of hash n lives in slot
 // c ^ ((n>>1)&7) so that a wave's ds_read_b128 of one chunk of 32 consecutive hashes is
 // bank-conflict free. An MFMA operand for k-step s is chunk 2s+(lane>>5) of hash
@@ -32,6 +32,7 @@
 #include <mutex>
 
 #include "hvd_devhash.h"
+#include "hvd_fp4.h"
 #include "hvd_kernels.h"
 
 namespace {
@@ -47,120 +48,6 @@ __device__ __forceinline__ v16f mfma_fp4(v4i a, v4i b, v16f c) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa, xb, c, 4, 4, 0, 0, 0, 0);
 }
 
-__device__ __forceinline__ uint32_t img_slot(uint32_t hash, uint32_t chunk) { return chunk ^ ((hash >> 1) & 7u); }
-
-// One thread per (hash, chunk). Rows >= n (padding up to n_pad) become FP4 zeros.
-__global__ __launch_bounds__(256) void k_expand_fp4(const uint32_t* __restrict__ db, uint32_t n, uint32_t n_pad,
-                                                    uint4* __restrict__ img, uint32_t code) {
-    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (idx >= (uint64_t)n_pad * 8u) return;
-    const uint32_t hash = (uint32_t)(idx >> 3), chunk = (uint32_t)(idx & 7u);
-    uint32_t o[4] = {0u, 0u, 0u, 0u};
-    if (hash < n) {
-        const uint32_t w = db[(size_t)hash * 8u + chunk];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            uint32_t x = 0x11111111u * code;  // +v in every nibble (code 2 = +1.0)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) x |= ((w >> (8 * d + t)) & 1u) << (4 * t + 3);  // bit set -> sign -> -1.0
-            o[d] = x;
-        }
-    }
-    img[(size_t)hash * 8u + img_slot(hash, chunk)] = make_uint4(o[0], o[1], o[2], o[3]);
-}
-
-// The inverse: the packed 32-byte hashes of an FP4 image (one thread per (hash, chunk): 32 sign nibbles -> 32 bits). The
-// pair-queue form settles its candidates on packed hashes (16 B per half instead of 64); callers that hand the library
-// only images (video search, cross search) get them derived here. Rows >= n are not written.
-__global__ __launch_bounds__(256) void k_pack_fp4(const uint4* __restrict__ img, uint32_t n, uint32_t* __restrict__ db) {
-    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (idx >= (uint64_t)n * 8u) return;
-    const uint32_t hash = (uint32_t)(idx >> 3), chunk = (uint32_t)(idx & 7u);
-    const uint4 v = img[(size_t)hash * 8u + img_slot(hash, chunk)];
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-    uint32_t w = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) w |= ((d[k] >> (4 * t + 3)) & 1u) << (8 * k + t);
-    db[(size_t)hash * 8u + chunk] = w;
-}
-
-// ---- data-dependent bit order (round 5) ---------------------------------------------------------------------------------
-// Hamming distance does not care in which order the bits of the hashes are written, as long as it is the same order for
-// everybody. The 128-bit first stage does: it sees the first 128 bits, and on real frame hashes some bits move together (on the
-// config-5 frames: DCT rows and columns 7..9), so unrelated frames agree on them far more often than on independent bits. The
-// video search therefore measures, on a sample of the library, how much every bit correlates with the others, keeps the 128
-// least entangled bits for the first stage (hvd_api.cpp: 128 times, drop the bit with the largest sum of |correlation| with the
-// bits still in the set) and rewrites packed hashes and FP4 image in that order: 7e-6 of the unrelated pairs pass instead of
-// 7.5e-5 (bits 0..63 + 192..255) or 2.3e-4 (bits 0..127). Results are bit-identical by construction.
-//   k_bit_rows: the sample, transposed -- rows[b][w] = bit b of sample hashes 64w .. 64w+63 (one ballot per bit and wave)
-//   k_bit_cooc: cooc[i][j] = number of sample hashes with bits i and j both set (diagonal: with bit i set)
-//   k_reorder_bits: packed hashes -> packed hashes and FP4 image in the new order: bit k of the output = bit perm[k] of the input
-__global__ __launch_bounds__(256) void k_bit_rows(const uint32_t* __restrict__ db, uint32_t stride, uint32_t words,
-                                                  unsigned long long* __restrict__ rows) {
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (wave >= words) return;  // (wave-uniform)
-    const uint32_t* h = db + (size_t)(wave * 64u + lane) * stride * 8u;
-    uint32_t w[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = h[k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-#pragma unroll 4
-        for (int t = 0; t < 32; ++t) {
-            const unsigned long long m = __ballot((w[k] >> t) & 1u);
-            if (lane == 0u) rows[(size_t)(32 * k + t) * words + wave] = m;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_bit_cooc(const unsigned long long* __restrict__ rows, uint32_t words,
-                                                  uint32_t* __restrict__ cooc) {
-    const uint32_t i = blockIdx.x, j = threadIdx.x;
-    const unsigned long long* ri = rows + (size_t)i * words;  // (block-uniform: scalar loads)
-    const unsigned long long* rj = rows + (size_t)j * words;
-    uint32_t c = 0;
-    for (uint32_t w = 0; w < words; ++w) c += (uint32_t)__popcll(ri[w] & rj[w]);
-    cooc[i * 256u + j] = c;
-}
-
-struct BitOrder {
-    uint8_t p[256];
-};
-// One thread per (hash, chunk) as in k_expand_fp4; a block's 32 hashes are staged in LDS, from where every thread gathers
-// its 32 bits. Rows >= n of the image (padding up to n_pad) become FP4 zeros; bits_out has n rows.
-__global__ __launch_bounds__(256) void k_reorder_bits(const uint32_t* __restrict__ bits_in, uint32_t n, uint32_t n_pad,
-                                                      const BitOrder order, uint32_t* __restrict__ bits_out,
-                                                      uint4* __restrict__ img, uint32_t code) {
-    __shared__ uint32_t src[256];
-    __shared__ uint8_t perm[256];
-    const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const uint32_t hash = (uint32_t)(idx >> 3), chunk = (uint32_t)(idx & 7u);
-    perm[threadIdx.x] = order.p[threadIdx.x];
-    src[threadIdx.x] = hash < n ? bits_in[(size_t)hash * 8u + chunk] : 0u;
-    __syncthreads();
-    if (idx >= (uint64_t)n_pad * 8u) return;
-    uint32_t o[4] = {0u, 0u, 0u, 0u};
-    if (hash < n) {
-        const uint32_t* mine = src + (threadIdx.x & ~7u);  // the eight words of this thread's hash
-        uint32_t w = 0;
-#pragma unroll 8
-        for (uint32_t t = 0; t < 32u; ++t) {
-            const uint32_t b = perm[32u * chunk + t];
-            w |= ((mine[b >> 5] >> (b & 31u)) & 1u) << t;
-        }
-        bits_out[(size_t)hash * 8u + chunk] = w;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            uint32_t x = 0x11111111u * code;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) x |= ((w >> (8 * d + t)) & 1u) << (4 * t + 3);
-            o[d] = x;
-        }
-    }
-    img[(size_t)hash * 8u + img_slot(hash, chunk)] = make_uint4(o[0], o[1], o[2], o[3]);
-}
 
 // Max of the 16 accumulator registers, taken on the BIT PATTERNS as signed integers:
 // for a positive threshold, "float >= thr" and "bits >= thr_bits" agree (negative floats
@@ -267,7 +154,7 @@ struct HitCtx {
     unsigned long long* count;
     hvd::VideoSink vs;
     uint32_t n, nq;
-    float thr_full, inv_scale2;
+    float thr_full;  // 256 - 2 * max_dist: a dot product at or above it is a hit
     uint32_t rect;
     float acc_start;  // start value of the launched form's accumulators (see or16_bits)
     const uint4* img_q;  // FP4 images of the rows / of the columns (the pair queue's drain reads single hashes from them)
@@ -362,7 +249,7 @@ __device__ __forceinline__ void tile_hits_body(const v16f& acc, uint32_t row0, u
         bool ok = dot >= c.thr_full && j < c.n && (rect ? i < c.nq : i < j);
         if (ok && c.group != nullptr) ok = c.group[i] != gcol;
         if (!video) {
-            if (ok) append_pair_wg(c.out, c.cap, c.count, i, j, (uint32_t)(256 - (int)(dot * c.inv_scale2)) >> 1);
+            if (ok) append_pair_wg(c.out, c.cap, c.count, i, j, (uint32_t)(256 - (int)dot) >> 1);
             continue;
         }
         const unsigned long long rowhits = __ballot(ok);
@@ -750,7 +637,7 @@ template <int TILES, int NBR, int S1, bool RECT, bool QUEUE = false>
 // (the 4-tile register form is held to 3 waves per SIMD = 168 VGPRs: with the pre-read fragment it would take 170)
 __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE) ? 3 : 2) void k_allpairs_mfma(const uint4* __restrict__ img, uint32_t n, uint32_t n_pad,
                                                           uint32_t max_dist, uint32_t col_chunk, uint32_t rank,
-                                                          uint32_t world, const uint4* __restrict__ img_q, float scale2,
+                                                          uint32_t world, const uint4* __restrict__ img_q,
                                                           const HitCtx* __restrict__ ctx,
                                                           const uint32_t* __restrict__ select, uint32_t select_id, uint32_t sel_arg) {
     static_assert(S1 == 2 || S1 == 4, "first stage = 128 or 256 bits");
@@ -820,12 +707,11 @@ __global__ __launch_bounds__(256, ((TILES == 4 && NBR == 4 && S1 == 2) || QUEUE)
         }
     }
 
-    // every product is +-v*v = +-scale2, so all dot products (and thresholds) scale by scale2.
     // first stage: acc = c1 - dot over 64*S1 bits, hit candidate <=> acc < 0; the second stage of the register form
-    // goes on to acc = c1 - dot256, a hit <=> dot256 >= 256 - 2*max_dist <=> acc <= c1 - thr_full = -129*scale2 (S1 = 2)
-    const float c1 = scale2 * ((float)(64 * S1) - 2.0f * (float)max_dist - 1.0f);
-    const float hit2 = -128.5f * scale2;
-    const float hit192 = -64.5f * scale2;  // after 192 bits: dot192 >= 192 - 2*max_dist <=> acc <= c1 - that = -65*scale2
+    // goes on to acc = c1 - dot256, a hit <=> dot256 >= 256 - 2*max_dist <=> acc <= c1 - thr_full = -129 (S1 = 2)
+    const float c1 = (float)(64 * S1) - 2.0f * (float)max_dist - 1.0f;
+    const float hit2 = -128.5f;
+    const float hit192 = -64.5f;  // after 192 bits: dot192 >= 192 - 2*max_dist <=> acc <= c1 - that = -65
     // marks' = marks << 1 | verdict(acc): v_alignbit_b32 takes the sign bit of the OR straight into the mask
     auto stage1_mark = [&](uint32_t marks, const v16f& acc) -> uint32_t {
         return __builtin_amdgcn_alignbit(marks, (uint32_t)or16_bits(acc), 31);
@@ -1129,58 +1015,18 @@ namespace hvd {
 
 static uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 
-uint32_t fp4_rows_padded(uint32_t n) { return round_up(n ? n : 1, 1024u); }
-
-// e2m1 code of the magnitude used for the +-v image: 1 = 0.5, 2 = 1.0 (default), 4 = 2.0, 6 = 4.0.
-// Any of them is exact; the choice only changes what toggles in the multiplier array (power -> clock).
-uint32_t g_fp4_code = 2;
 constexpr int kClkWord = 192;  // 32-bit word offset of the clock telemetry's accumulators in a context's select buffer (byte 768)
-static float fp4_scale2() {
-    const float v = g_fp4_code == 1 ? 0.5f : g_fp4_code == 2 ? 1.0f : g_fp4_code == 4 ? 2.0f : 4.0f;
-    return v * v;
-}
 
-hipError_t launch_expand_fp4(const void* d_db, uint32_t n, void* d_img, hipStream_t s) {
-    const uint32_t n_pad = fp4_rows_padded(n);
-    const uint64_t threads = (uint64_t)n_pad * 8u;
-    hipLaunchKernelGGL(k_expand_fp4, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_db, n,
-                       n_pad, (uint4*)d_img, g_fp4_code);
-    return hipGetLastError();
-}
 
 // auto variant (13): the form for data with common false survivors (18 = panel-mark queue; 0 = none, i.e. round 3's two-way
 // choice) and the survivor density (per 1024-pair tile, as the probe estimates it) up to which it is preferred over the register form
-uint32_t g_mfma_lds_pad = 0;  // occupancy experiments: unused dynamic LDS per workgroup (hvd_debug_set "mfma_lds_pad")
 uint32_t g_mfma_queue_packed = 1;  // 0: the pair queue settles from the FP4 images even when packed hashes are at hand (tests)
 uint32_t g_mfma_auto_mid = 18;
 int g_mfma_force_sel = -1;  // hvd_debug_set "mfma_force_sel": -1 the probe chooses (explicit forms: bits 0..127); 0 | 1 | 2 forced
 uint32_t g_mfma_auto_mid_max_x100 = 500;  // (scripts/gpu_k2_rate_sweep.py: the panel-mark queue takes 0.61-0.67 of the register form's time
                                           // at 1-2.7 survivors per tile, 0.79 at 4, 0.88 at 5.3, 1.23 at 8; round 4's first queue form, 15,
                                           // won up to ~1 and the boundary was 1.3)
-hipError_t launch_pack_fp4(const void* d_img, uint32_t n, void* d_db, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    const uint64_t threads = (uint64_t)n * 8u;
-    hipLaunchKernelGGL(k_pack_fp4, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const uint4*)d_img, n, (uint32_t*)d_db);
-    return hipGetLastError();
-}
 
-// sample -> co-occurrence counts (k_bit_rows + k_bit_cooc): d_rows 256 * words u64, d_cooc 256 * 256 u32
-hipError_t launch_bit_cooc(const void* d_bits, uint32_t stride, uint32_t words, void* d_rows, void* d_cooc, hipStream_t s) {
-    hipLaunchKernelGGL(k_bit_rows, dim3((words + 3u) / 4u), dim3(256), 0, s, (const uint32_t*)d_bits, stride, words, (unsigned long long*)d_rows);
-    hipLaunchKernelGGL(k_bit_cooc, dim3(256), dim3(256), 0, s, (const unsigned long long*)d_rows, words, (uint32_t*)d_cooc);
-    return hipGetLastError();
-}
-
-// packed hashes -> packed hashes + FP4 image with bit k = input bit perm[k] (perm MUST be a permutation of 0..255: the caller checks)
-hipError_t launch_reorder_bits(const void* d_bits_in, uint32_t n, const uint8_t perm[256], void* d_bits_out, void* d_img, hipStream_t s) {
-    const uint32_t n_pad = fp4_rows_padded(n);
-    BitOrder o;
-    memcpy(o.p, perm, 256);
-    const uint64_t threads = (uint64_t)n_pad * 8u;
-    hipLaunchKernelGGL(k_reorder_bits, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, (const uint32_t*)d_bits_in, n, n_pad, o,
-                       (uint32_t*)d_bits_out, (uint4*)d_img, g_fp4_code);
-    return hipGetLastError();
-}
 
 uint32_t g_mfma_col_chunk_max = 8192;  // tuning knob (hvd_debug_set "mfma_col_chunk_max"); 2048..32768 within 3 %
 
@@ -1230,10 +1076,9 @@ static HitCtx hit_ctx(const AllPairsArgs& a, bool rect, uint32_t nq, const int32
     c.vs = a.sink;
     c.n = a.n;
     c.nq = nq;
-    c.thr_full = fp4_scale2() * (256.0f - 2.0f * (float)a.max_dist);
-    c.inv_scale2 = 1.0f / fp4_scale2();
+    c.thr_full = 256.0f - 2.0f * (float)a.max_dist;
     c.rect = rect ? 1u : 0u;
-    c.acc_start = fp4_scale2() * ((float)(64 * s1) - 2.0f * (float)a.max_dist - 1.0f);
+    c.acc_start = (float)(64 * s1) - 2.0f * (float)a.max_dist - 1.0f;
     c.img_q = (const uint4*)d_img_q;
     c.img_t = (const uint4*)d_img_t;
     c.db_t = (const uint4*)a.d_db;
@@ -1276,12 +1121,12 @@ static hipError_t launch_form(const AllPairsArgs& a, const void* d_img, bool rec
         hipLaunchKernelGGL(k_set_hit_ctx, dim3(1), dim3(1), 0, s, ctx, hit_ctx(a, rect, nq, d_group_t, S1, rect ? d_img_q : d_img, d_img),
                            (uint32_t*)nullptr);
     if (rect)
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE>), grid, dim3(256), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
-                           a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, fp4_scale2(), ctx, d_select,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, true, QUEUE>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+                           a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)d_img_q, ctx, d_select,
                            select_id, (uint32_t)(g_mfma_force_sel > 0 ? g_mfma_force_sel : 0));
     else
-        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE>), grid, dim3(256), g_mfma_lds_pad, s, (const uint4*)d_img, a.n, n_pad,
-                           a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)nullptr, fp4_scale2(), ctx, d_select,
+        hipLaunchKernelGGL((k_allpairs_mfma<T, NBR, S1, false, QUEUE>), grid, dim3(256), 0, s, (const uint4*)d_img, a.n, n_pad,
+                           a.max_dist, (uint32_t)chunk, a.rank, a.world, (const uint4*)nullptr, ctx, d_select,
                            select_id, (uint32_t)(g_mfma_force_sel > 0 ? g_mfma_force_sel : 0));
     return hipGetLastError();
 }

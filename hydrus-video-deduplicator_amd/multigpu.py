@@ -48,6 +48,76 @@ def tiles_of_rank(n: int, rank: int, world: int, variant: int = 9):
             yield row0, min(row0 + rows, n), col0, col1
 
 
+def rank_work_shares(n: int, world: int, variant: int = 9, tiles: bool = False) -> np.ndarray:
+    """Work of every rank in one all-pairs pass over n hashes, in (row block x 128-candidate super-panel) steps -- what
+    k_allpairs_mfma walks: tile (rb, cb) belongs to rank (rb + cb) % world and starts at the super-panel that holds its
+    first row + 1 (candidates at or below the diagonal are skipped 128 at a time). Host arithmetic only; the exact
+    statement of the load balance a sharded pass can reach. tiles=True: the number of workgroups with work per rank."""
+    rows, chunk = tile_geometry(n, variant)
+    n_pad = (max(n, 1) + 1023) // 1024 * 1024
+    n_rb, n_cb = (n + rows - 1) // rows, (n_pad + chunk - 1) // chunk
+    rb = np.arange(n_rb, dtype=np.int64)[:, None]
+    cb = np.arange(n_cb, dtype=np.int64)[None, :]
+    row0, col0 = rb * rows, cb * chunk
+    col1 = np.minimum(col0 + chunk, n_pad)
+    j0 = np.maximum(col0, (row0 + 1) // 128 * 128)
+    steps = np.where(np.minimum(col1, n) <= row0 + 1, 0, np.maximum(col1 - j0, 0) // 128)
+    owner = (rb + cb) % world
+    if tiles:
+        return np.bincount(owner.ravel(), weights=(steps.ravel() > 0).astype(np.float64), minlength=world)
+    return np.bincount(owner.ravel(), weights=steps.ravel().astype(np.float64), minlength=world)
+
+
+# What the first N > 1 run is to be held against (VERDICT r5 item 6): measured at N = 1 on driver-class boxes (round 6:
+# BENCH line + profiles/r06_bench_kernel_stats.csv), nothing here is fitted to a multi-GPU run -- none exists.
+SCALING_MODEL = {
+    "kernel_ms_per_1e11_cmp": 3.62,   # 18.1 ms per 4.999995e11 comparisons (17.6 - 19.0 by box: power-limited clock)
+    "expand_ms_per_1e6_hashes": 0.028,  # k_expand_fp4: every rank rebuilds the image of the WHOLE replicated DB
+    "probe_and_empty_launches_ms": 0.13,  # probe 0.048 + the two unchosen forms' empty launches 0.051 + 0.027 + context 0.004
+    "readback_ms": 0.03,              # pair count + this rank's records
+    "exchange_ms": 0.08,              # ONE all-gather of a 16 KiB slot per rank + read-back of world x 16 KiB (RCCL, small messages)
+    "host_ms": 0.10,                  # Python, ctypes, launch latency (host_ms of the N = 1 line)
+    "resident_workgroups": 768,       # 3 per CU (168 VGPRs): a launch ends with about half a round of them draining
+    "tail_rounds": 0.5,
+}
+
+
+def predict_step(n: int, world: int, model: dict | None = None, variant: int = 9) -> dict:
+    """Predicted time of one all-pairs step over n hashes on `world` GPUs from the N = 1 measurements above and the exact
+    tile partition: the slowest rank's kernel share + the fixed per-step pieces."""
+    m = dict(SCALING_MODEL, **(model or {}))
+    shares = rank_work_shares(n, world, variant)
+    total_cmp = n * (n - 1) / 2.0
+    worst = float(shares.max() / shares.sum()) if shares.sum() else 1.0 / world
+    # the constant was measured on 1 M hashes at N = 1 (60 k workgroups = 78 rounds of the resident 768): a rank with fewer
+    # workgroups pays the same half round of tail over fewer rounds
+    tail = lambda wgs: 1.0 + m["tail_rounds"] * m["resident_workgroups"] / max(wgs, 1.0)  # noqa: E731
+    wgs = float(rank_work_shares(n, world, variant, tiles=True).max())
+    kernel = m["kernel_ms_per_1e11_cmp"] * total_cmp / 1e11 * worst * tail(wgs) / tail(60_000.0)
+    fixed = (m["expand_ms_per_1e6_hashes"] * n / 1e6 + m["probe_and_empty_launches_ms"] + m["readback_ms"] + m["host_ms"] +
+             (m["exchange_ms"] if world > 1 else 0.0))
+    return {"n_gpus": world, "n_hashes": n, "ms_per_step": round(kernel + fixed, 3), "kernel_ms": round(kernel, 3),
+            "fixed_ms": round(fixed, 3), "imbalance": round(worst * world, 4), "workgroups_of_slowest_rank": int(wgs),
+            "comparisons_per_s": float(f"{total_cmp / ((kernel + fixed) * 1e-3):.4g}")}
+
+
+def predict_scaling(n1: int = 1_000_000, worlds=(1, 2, 4, 8), mode: str = "weak", model: dict | None = None) -> list:
+    """The curve bench.py's `--mode weak|strong` would trace: weak = n1 * sqrt(N) hashes (comparisons per GPU fixed), strong =
+    n1 hashes at every N. `efficiency` = value(N) / (N x value(1))."""
+    import math
+
+    out = []
+    base = None
+    for w in worlds:
+        n = n1 if mode == "strong" or w == 1 else int(round(n1 * math.sqrt(w) / 1024.0)) * 1024
+        p = predict_step(n, w, model)
+        base = p if base is None else base
+        p["mode"] = mode
+        p["efficiency"] = round(p["comparisons_per_s"] / (w * base["comparisons_per_s"]), 3)
+        out.append(p)
+    return out
+
+
 def merge_pairs(parts) -> np.ndarray:
     """Concatenate per-rank records and sort by (i, j). Ranks own disjoint tiles, so there
     are no duplicates to remove; this asserts it."""

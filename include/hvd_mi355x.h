@@ -216,10 +216,10 @@ int hvd_get_pdq_dct_mode(void);
  *   "pdq_down512_wave" 0|1|2                               (wave-per-frame kernel: never | batches >= 704 | always)
  *   "pdq_down512_wave_grid" n                              (waves in flight; 0 = what is resident at once)
  *   "pdq_down512_strip" 0|32|64                            (workgroup-per-frame kernel's strip width: by batch size | 32 | 64)
- *   "fp4_code", "mfma_col_chunk_max"                       (FP4-MFMA Hamming kernel)
+ *   "mfma_col_chunk_max"                                   (FP4-MFMA Hamming kernel: largest column chunk of a tile)
  *   "mfma_auto_mid" 0|18, "mfma_auto_mid_max_x100" n       (auto variant: may it pick the panel-mark queue form -- 18 -- and the
  *                                                           survivor density per 1024-pair tile, x 0.01, up to which it does -- 500)
- *   "mfma_queue_packed" 0|1, "mfma_lds_pad" bytes          (pair queue settles from the FP4 images only; occupancy experiments)
+ *   "mfma_queue_packed" 0|1                                (0: the pair queue settles from the FP4 images only)
  *   "mfma_force_sel" -1|0|1|2                              (which 128 bits the first stage sees: the probe's choice | bits 0..127 |
  *                                                           128..255 | 0..63 + 192..255)
  *   "pdq_hash_grid" n, "pdq_hash_prefetch" 0|1             (64x64 hash kernel: forced grid; next frame fetched ahead, off)

@@ -16,7 +16,6 @@ nk = libr.n_frames
 img = libr.image()
 cap = 1 << 22
 if os.environ.get("CHUNK"): L.check(lib.hvd_debug_set(b"mfma_col_chunk_max", int(os.environ["CHUNK"])))
-if os.environ.get("LDS_PAD"): L.check(lib.hvd_debug_set(b"mfma_lds_pad", int(os.environ["LDS_PAD"])))
 d_pairs = L.DeviceBuffer(16 * cap); d_cnt = L.DeviceBuffer(8)
 print("kept frames", nk, "comparisons %.3g" % (nk * (nk - 1) / 2))
 for v in [int(x) for x in (sys.argv[1:] or ["12", "18", "8", "13"])]:

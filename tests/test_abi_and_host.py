@@ -347,3 +347,24 @@ def test_unverified_policies_are_labelled_and_warned_about_once(hvd, monkeypatch
         vpdq.warn_unverified_policies()
     assert not rec
     assert "(unverified)" not in vpdq.policy_labels()["comparator"]
+
+
+@pytest.mark.parametrize("n,world", [(300_000, 2), (300_000, 8), (1_000_000, 8), (77_777, 3)])
+def test_scaling_model_counts_every_step_of_the_pass_exactly_once(hvd, n, world):
+    """hvd_amd.multigpu.rank_work_shares / predict_step: the per-rank work the prediction rests on is the
+    kernel's own walk -- summed over the ranks it is the single-GPU walk, whatever the world size; the tile-cyclic deal is
+    balanced to well under a per cent; the predicted curve is monotone and its N = 1 point is the measured constant."""
+    M = hvd.multigpu
+    one = M.rank_work_shares(n, 1)
+    sh = M.rank_work_shares(n, world)
+    assert sh.sum() == one.sum() and one.sum() > 0
+    assert sh.max() / sh.mean() < 1.01
+    assert M.rank_work_shares(n, world, tiles=True).sum() == M.rank_work_shares(n, 1, tiles=True).sum()
+    p1, pw = M.predict_step(n, 1), M.predict_step(n, world)
+    assert pw["kernel_ms"] < p1["kernel_ms"] and pw["kernel_ms"] * world > p1["kernel_ms"] * 0.99
+    assert n < 300_000 or pw["ms_per_step"] < p1["ms_per_step"]  # (a tiny DB is all fixed cost: more GPUs add the exchange)
+    weak = M.predict_scaling(mode="weak")
+    strong = M.predict_scaling(mode="strong")
+    assert [p["n_gpus"] for p in weak] == [1, 2, 4, 8] and weak[0]["efficiency"] == 1.0
+    assert all(a["efficiency"] >= b["efficiency"] for a, b in zip(strong, strong[1:]))
+    assert abs(weak[0]["kernel_ms"] - M.SCALING_MODEL["kernel_ms_per_1e11_cmp"] * 4.999995) < 0.01

@@ -117,6 +117,10 @@ def test_bench_self_launches_two_ranks_on_one_gpu(gpu):
     assert sum(p["pairs"] for p in out["per_rank"]) == out["config"]["pairs_found"]
     assert "scale_metric" in out and out["scaling"] == "weak"
     _check_breakdown(out, steps=2, world=2)
+    # the prediction the first real N > 1 line is to be held against rides in the line itself
+    pred = out["predicted"]
+    assert pred["n_gpus"] == 2 and pred["n_hashes"] == out["config"]["n_hashes"] and pred["ms_per_step"] > 0
+    assert 0.5 < pred["efficiency"] <= 1.0 and 0.99 < pred["imbalance"] < 1.05 and pred["measured_over_predicted"] > 0
     assert b"import torch" not in open(os.path.join(ROOT, "bench.py"), "rb").read()
 
 

@@ -69,17 +69,16 @@ def shapes(tmp_path_factory):
     if not (os.path.exists(HIPCC) and shutil.which("c++filt")):
         pytest.fail("hipcc / c++filt missing: the code-shape guard cannot run (it must, on the build container)")
     tmp = str(tmp_path_factory.mktemp("code_shape"))
-    return {"mfma": _compile("k_hamming_mfma.hip", tmp), "pdq": _compile("k_pdq.hip", tmp)}
+    return {"mfma": _compile("k_hamming_mfma.hip", tmp), "pdq": _compile("k_pdq.hip", tmp), "img": _compile("k_fp4_image.hip", tmp)}
 
 
 # form -> template arguments <TILES, NBR, S1, RECT, QUEUE> (k_hamming_mfma.hip: launch table), what the form must keep:
-# waves = resident waves per SIMD, spill = VGPR spills allowed (0 everywhere but form 12's cold path), lds = bytes.
+# waves = resident waves per SIMD, spill = VGPR spills allowed (0 everywhere), lds = bytes.
 # Round 6: the table holds only the forms that have a job (the eleven measured-and-lost ones are in HISTORY.md).
 FORMS = {
     8: ("8, 4, 4, {r}, false", dict(waves=2, spill=0, lds=40992)),   # full 256-bit compare, no first stage: the reference form
     9: ("8, 2, 2, {r}, false", dict(waves=3, spill=0, lds=40992)),   # fetch form: the probe's pick for uniform DBs (headline)
-    12: ("4, 4, 2, {r}, false", dict(waves=3, spill=2, lds=40992)),  # register cascade: the probe's pick for dense DBs; 2 spills
-                                                                     # pinned, in the cold path only (test below)
+    12: ("4, 4, 2, {r}, false", dict(waves=3, spill=0, lds=40992)),  # register cascade: the probe's pick for dense DBs
     18: ("8, 2, 2, {r}, true", dict(waves=3, spill=0, lds=53344)),   # panel-mark queue: the probe's pick for frame hashes
 }
 DEFAULT_FORMS = (9, 12, 18)  # what the auto variant (13) can run
@@ -106,27 +105,14 @@ def test_allpairs_form_keeps_its_occupancy(shapes, form, rect):
 
 
 def test_default_forms_have_no_spill_traffic_in_the_loop_and_three_waves(shapes):
-    """Forms 9 and 18 spill nothing. Form 12 (held to 168 VGPRs by its launch bounds; it would take 170) spills the two
-    loop-invariant LDS addresses of the 256-bit step's B fragment (one per panel buffer): stored once in front of the loop,
-    reloaded only where a tile has survived 192 bits -- each reload feeds the ds_read_b128 of that step's MFMA directly."""
+    """Forms 9, 12 and 18 -- what the probe can pick -- spill nothing and keep three resident waves per SIMD (until round 5
+    form 12 parked two loop-invariant LDS addresses in scratch; without the operand-scale parameter of the removed fp4_code
+    experiment it fits its 168 registers)."""
     for form in DEFAULT_FORMS:
         for rect in ("false", "true"):
             k = shapes["mfma"][f"k_allpairs_mfma<{FORMS[form][0].format(r=rect)}>"]
             assert k["vgpr"] <= 168, (form, rect, k["vgpr"])
-            if form != 12:
-                assert k["vgpr_spill"] == 0 and "scratch_" not in k["isa"], (form, rect, k["vgpr_spill"])
-                continue
-            lines = [ln.strip() for ln in k["isa"].splitlines() if ln.strip() and not ln.strip().startswith(";")]
-            stores = [i for i, ln in enumerate(lines) if ln.startswith("scratch_store")]
-            loads = [i for i, ln in enumerate(lines) if ln.startswith("scratch_load")]
-            assert len(stores) == 2 and len(loads) == 8  # 2 addresses; 4 tiles x 2 panel buffers
-            first_mfma = next(i for i, ln in enumerate(lines) if ln.startswith("v_mfma"))
-            assert max(stores) < first_mfma  # stored before the loop
-            for i in loads:  # reload -> (wait, add) -> ds_read_b128 -> the 256-bit step's MFMA
-                nxt = lines[i + 1:i + 8]
-                assert any(x.startswith("ds_read_b128") for x in nxt) and any(x.startswith("v_mfma") for x in nxt), nxt
-                prev = lines[max(0, i - 12):i]
-                assert any(x.startswith("s_cbranch") for x in prev) and any(x.startswith("v_cmp_lt_f32") for x in prev), prev
+            assert k["vgpr_spill"] == 0 and "scratch_" not in k["isa"], (form, rect, k["vgpr_spill"])
 
 
 def test_every_allpairs_instantiation_is_in_the_table(shapes):
@@ -139,8 +125,9 @@ def test_probe_and_image_kernels(shapes):
     m = shapes["mfma"]
     # (round 5: a third survivor count -- 137 VGPRs = 3 waves per SIMD; capped at 128 it spills 17, and the probe is 0.3 % of a pass)
     assert waves_per_simd(m["k_prefilter_probe"]["vgpr"]) >= 3 and m["k_prefilter_probe"]["vgpr_spill"] == 0
-    for name in ("k_expand_fp4", "k_pack_fp4"):
-        assert waves_per_simd(m[name]["vgpr"]) == 8 and m[name]["lds"] == 0 and m[name]["vgpr_spill"] == 0
+    for name in ("k_expand_fp4", "k_pack_fp4"):  # (csrc/k_fp4_image.hip since round 6)
+        k = shapes["img"][name]
+        assert waves_per_simd(k["vgpr"]) == 8 and k["lds"] == 0 and k["vgpr_spill"] == 0
 
 
 # k_pdq_hash64<KIND, DLDS, LUT, PREF>: KIND 0 = u8 gray in, 1 = float luma in (after the down-sampler); DLDS 2 = DCT matrix as
