@@ -11,7 +11,7 @@ FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=
 # (.cpp units go through hipcc too: csrc/Makefile)
 ( cd $SRC && /opt/rocm/bin/hipcc $FLAGS "$@" -c $UNIT -o $OUT/${UNIT%.*}_$NAME.o )
 OBJS=""
-for o in hvd_api hvd_stream k_hamming k_hamming_mfma k_fp4_image k_vmatch k_synth k_pdq; do
+for o in hvd_api hvd_search hvd_comm hvd_stream k_hamming k_hamming_mfma k_fp4_image k_vmatch k_synth k_pdq; do
   if [ "$o" = "${UNIT%.*}" ]; then OBJS="$OBJS $OUT/${o}_$NAME.o"; else OBJS="$OBJS $SRC/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $OBJS -shared -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o $OUT/libhvd_$NAME.so
