@@ -1008,14 +1008,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-#ifndef HVD_F1_STATE_AUX
-#define HVD_F1_STATE_AUX 0
-#endif
 __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t idx) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(idx * 4u), 0, HVD_F1_STATE_AUX));
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(idx * 4u), 0, 0));
 }
 __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t idx, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(idx * 4u), 0, HVD_F1_STATE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(idx * 4u), 0, 0);
 }
 
 
@@ -1023,10 +1020,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t idx, f
 // 16 g .. 16 g + 15 (piece u = 64 sub + lane of that 16-row group), so only NI/2 lane-dependent offsets exist;
 // the group offset rides in the scalar offset (loads) or the immediate offset (LDS).
 // cache policy of the frame loads
-#ifndef HVD_F1_FRAME_AUX
-#define HVD_F1_FRAME_AUX 0
-#endif
-constexpr int kFrameLoadAux = HVD_F1_FRAME_AUX;  // cache-policy bits (1 = sc0, 2 = nt, 16 = sc1); nt was measured slower (it also defeats the L2 reuse of shared sectors)
+constexpr int kFrameLoadAux = 0;  // cache-policy bits (1 = sc0, 2 = nt, 16 = sc1); nt was measured slower (it also defeats the L2 reuse of shared sectors)
 template <int CH>
 __device__ __forceinline__ void unit_fetch(__amdgpu_buffer_rsrc_t frame, const uint32_t soff, const int lane,
                                            uint4 (&p)[TileLoad<CH>::NI]) {
